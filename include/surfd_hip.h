@@ -1,0 +1,183 @@
+/*
+ * surfd_hip.h — C ABI of libsurfd_hip.so: the MI355X (gfx950) implementation of Surf-D's
+ * sampling hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (Yzmblog/SurfD) has no FFI layer: its boundary is the set of Python call
+ * signatures used by sample/generate_*.py.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference root); INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative surfd_status; the message is
+ *    available from surfd_last_error() (thread-local).  No exceptions, no abort().
+ *  - all device buffers are owned by the caller (torch), contiguous, fp32 unless noted;
+ *    the library owns only re-laid-out private weight copies and a workspace arena.
+ *  - all work is enqueued on the caller's hipStream_t (passed as void*); functions do
+ *    not synchronise unless documented ("host-sync").
+ *  - handles are bound to the device current at create time; one handle per process/rank.
+ */
+#ifndef SURFD_HIP_H
+#define SURFD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SURFD_OK = 0,
+    SURFD_ERR_ARG = -1,        /* bad shape / null pointer / unknown key      */
+    SURFD_ERR_STATE = -2,      /* missing parameter, latents not bound, ...   */
+    SURFD_ERR_HIP = -3,        /* a HIP runtime call failed                   */
+    SURFD_ERR_UNSUPPORTED = -4 /* configuration outside what the path covers  */
+} surfd_status;
+
+typedef void *surfd_stream;    /* hipStream_t */
+typedef struct surfd_unet surfd_unet;
+typedef struct surfd_decoder surfd_decoder;
+typedef struct surfd_grid surfd_grid;
+
+const char *surfd_last_error(void);
+int surfd_abi_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int surfd_device_count(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Denoiser: UNetModel (models/openaimodel.py:413-749) as configured by MDM             */
+/* (models/mdm.py:34-57).                                                               */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int in_channels, model_channels, out_channels, num_res_blocks;
+    int n_mult, channel_mult[8];
+    int n_attn, attention_resolutions[8];
+    int num_heads;
+    int context_dim;   /* 0: no sketch_emb */
+    int num_classes;   /* 0: no label_emb  */
+} surfd_unet_cfg;
+
+/* Builds the execution plan on the host (no device needed).  Replaces
+ * UNetModel.__init__ (openaimodel.py:443-692). */
+int surfd_unet_create(const surfd_unet_cfg *cfg, surfd_unet **out);
+void surfd_unet_destroy(surfd_unet *u);
+/* state_dict layout the handle expects (keys relative to "Unet.", reference order):
+ * lets the host build its nn.Module / check a checkpoint without a device. */
+int surfd_unet_num_params(const surfd_unet *u);
+int surfd_unet_param_info(const surfd_unet *u, int i, const char **key, int64_t shape[4], int *ndim);
+/* One call per state_dict tensor (load_model_wo_clip, utils/model_util.py:6-9).
+ * dev_ptr: device fp32, contiguous; repacked into the private MFMA fragment layout. */
+int surfd_unet_set_param(surfd_unet *u, const char *key, const void *dev_ptr,
+                         const int64_t *shape, int ndim, surfd_stream s);
+/* fails with SURFD_ERR_STATE naming the first tensor that was never set */
+int surfd_unet_finalize(surfd_unet *u, surfd_stream s);
+/* UNetModel.forward (openaimodel.py:710-749) / MDM.forward (mdm.py:91-110):
+ * x[B,1,L], t[B] (int64, original-scale timesteps), ctx[B,context_dim] or NULL,
+ * cls[B] (int64) or NULL -> out[B,1,L].  All device pointers. */
+int surfd_unet_forward(surfd_unet *u, const float *x, const int64_t *t, const float *ctx,
+                       const int64_t *cls, float *out, int B, int L, surfd_stream s);
+
+/* ------------------------------------------------------------------------------------ */
+/* Reverse loop: p_sample_loop / ddim_sample_loop                                       */
+/* (diffusion/gaussian_diffusion.py:570-708, 858-972; diffusion/respace.py:63-132).      */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int sampler;            /* 0 = DDPM ancestral (p_sample :471-520), 1 = DDIM (:711-761) */
+    int num_steps;          /* T' (after respacing)                                         */
+    int clip_denoised;      /* clamp x0 to [-1,1] (process_xstart :330-336)                 */
+    float eta;              /* DDIM only                                                    */
+    const int64_t *timestep_map;   /* host [T']: loop index -> original timestep (respace.py:123-128) */
+    /* host float32 tables [T'], already cast float64->float32 as _extract_into_tensor does (:1339) */
+    const float *coef1, *coef2, *log_variance;                /* DDPM */
+    const float *sqrt_recip_ab, *sqrt_recipm1_ab, *ab, *ab_prev;   /* DDIM */
+} surfd_sampler_cfg;
+
+/* Whole reverse loop without returning to the host: noise[T'+1,B,1,L] (row 0 = x_T,
+ * row 1+k = z of loop iteration k), ctx/cls as in surfd_unet_forward (constant over the
+ * loop), x_out[B,1,L]; traj (nullable) [T',B,1,L] receives x after every iteration. */
+int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise,
+                      const float *ctx, const int64_t *cls, float *x_out, float *traj,
+                      int B, int L, surfd_stream s);
+/* single posterior updates on n elements (used by the generic Python loop) */
+int surfd_ddpm_step(const float *x_t, const float *x0, const float *z, float coef1, float coef2,
+                    float log_variance, int t_nonzero, int clip_denoised, float *out, int64_t n,
+                    surfd_stream s);
+int surfd_ddim_step(const float *x_t, const float *x0, const float *z, float sqrt_recip_ab,
+                    float sqrt_recipm1_ab, float ab, float ab_prev, float eta, int t_nonzero,
+                    int clip_denoised, float *out, int64_t n, surfd_stream s);
+
+/* ------------------------------------------------------------------------------------ */
+/* UDF field: CoordsEncoder.encode (AutoEncoder/models/coordsenc.py:25-51) +             */
+/* CbnDecoder.forward (AutoEncoder/models/cbndec.py:35-47,127-134) + the udf_func        */
+/* closure (sample/generate_uncond.py:96-101) + sample_grads (meshudf/meshudf.py:231-251) */
+/* ------------------------------------------------------------------------------------ */
+int surfd_decoder_create(int input_dim, int latent_dim, int hidden_dim, int num_blocks,
+                         surfd_decoder **out);
+void surfd_decoder_destroy(surfd_decoder *d);
+int surfd_decoder_num_params(const surfd_decoder *d);
+int surfd_decoder_param_info(const surfd_decoder *d, int i, const char **key, int64_t shape[4], int *ndim);
+/* keys exactly as in ckpt["decoder"] ("decoder.fc_p.weight", ...); num_batches_tracked is
+ * accepted and ignored (dev_ptr may be NULL for it). */
+int surfd_decoder_set_param(surfd_decoder *d, const char *key, const void *dev_ptr,
+                            const int64_t *shape, int ndim, surfd_stream s);
+int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s);
+/* lat[S,D]: computes the per-sample conditional-BN scale/shift tables [S,11,2,H]
+ * (the 22 per-point Conv1d(D->H) of cbndec.py:74-79 collapse to this when one latent is
+ * broadcast to all points, cbndec.py:131-132). */
+int surfd_decoder_bind_latents(surfd_decoder *d, const float *lat, int S, surfd_stream s);
+/* CbnDecoder.forward on pre-encoded coordinates emb[n,input_dim] -> logits[n] */
+int surfd_decoder_logits_emb(surfd_decoder *d, int sample, const float *emb, int64_t n,
+                             float *logits, surfd_stream s);
+/* udf_func: pts[n,3] -> udf[n] = (1 - sigmoid(decoder(encode(p), lat))) * 0.1;
+ * logits (nullable) receives the raw decoder output */
+int surfd_decoder_udf(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf,
+                      float *logits, surfd_stream s);
+/* sample_grads: ngrad[n,3] = -normalize(d udf/d p) (eps 1e-12; exact zero vector where the
+ * fp32 sigmoid derivative vanishes); udf (nullable) as above */
+int surfd_decoder_udf_grad(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf,
+                           float *ngrad, surfd_stream s);
+
+/* ------------------------------------------------------------------------------------ */
+/* UDF grid: GridFiller / get_udf_and_grads (meshudf/meshudf.py:23-304)                  */
+/* ------------------------------------------------------------------------------------ */
+#define SURFD_GRID_MAX_LEVELS 8
+typedef struct {
+    int n_levels;
+    int levels[SURFD_GRID_MAX_LEVELS];
+    int64_t fwd_points[SURFD_GRID_MAX_LEVELS];   /* decoder forward queries per level */
+    int64_t grad_points;                         /* forward+backward queries          */
+} surfd_grid_stats;
+
+/* N = final resolution (power of two >= 64); allocates the per-level work lists. */
+int surfd_grid_create(int N, surfd_grid **out);
+void surfd_grid_destroy(surfd_grid *g);
+/* thresholds are computed by the host exactly as the reference's Python does and handed
+ * over as float32: refine[l] = float32(1.5*1.7*(2.0/levels[l])) (meshudf.py:185-188),
+ * grad = float32(2.5*2.0/N) (:200), voxel = float32(2.0/(N-1)) (:53), origin -1. */
+int surfd_grid_set_thresholds(surfd_grid *g, const float *refine, int n_levels, float grad_thr,
+                              float voxel, float origin);
+/* GridFiller.fill_grid fused with the native decoder: no host round trip, no Python.
+ * udf[N^3], grads[N^3*3] device outputs (grads may be NULL: watertight variant,
+ * utils/utils.py:151-339). */
+int surfd_grid_fill(surfd_grid *g, surfd_decoder *d, int sample, float *udf, float *grads,
+                    surfd_stream s);
+/* get_udf_and_grads (use_fast_grid_filler=False): all N^3 points, gradients where
+ * udf < grad_below (= max_dist - 1e-3 in the reference). */
+int surfd_grid_fill_dense(surfd_grid *g, surfd_decoder *d, int sample, float grad_below,
+                          float *udf, float *grads, surfd_stream s);
+/* host-sync: counters of the last fill on this handle */
+int surfd_grid_get_stats(surfd_grid *g, surfd_grid_stats *out, surfd_stream s);
+
+/* Same algorithm with an arbitrary host callable (the reference's udf_func contract):
+ * begin -> for each level { points -> [host evaluates] -> commit } -> grad_points ->
+ * [host differentiates] -> grad_commit.  *_points are host-sync (they return a count). */
+int surfd_grid_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s);
+int surfd_grid_level_points(surfd_grid *g, int level, float *xyz, int64_t capacity, int64_t *n,
+                            surfd_stream s);
+int surfd_grid_level_commit(surfd_grid *g, int level, const float *values, int64_t n, surfd_stream s);
+int surfd_grid_grad_points(surfd_grid *g, float *xyz, int64_t capacity, int64_t *n, surfd_stream s);
+int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURFD_HIP_H */

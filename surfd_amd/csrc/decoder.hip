@@ -1,0 +1,775 @@
+// Fused UDF field kernels for gfx950: positional encoding -> 11-layer conditional-BN
+// residual MLP -> sigmoid/UDF epilogue, and the same with an in-kernel analytic reverse
+// sweep for -normalize(d udf / d p).
+//
+// Replaces, per point tile, what the reference launches as 20 sin/cos + cat, 34 Conv1d(k=1),
+// 11 batch_norm, 11 ReLU (+ a full autograd backward for gradients):
+//   CoordsEncoder.encode          AutoEncoder/models/coordsenc.py:25-51
+//   DecoderConditionalBatchNorm   AutoEncoder/models/cbndec.py:35-47
+//   ConditionalBatchNorm1d        AutoEncoder/models/cbndec.py:68-82   (hoisted to a*x+b tables)
+//   ConditionalResnetBlock1d      AutoEncoder/models/cbndec.py:99-103
+//   udf_func                      sample/generate_uncond.py:96-101
+//   sample_grads                  meshudf/meshudf.py:231-251
+//
+// Kernel shape (MFMA-bound, exact fp32: v_mfma_f32_32x32x2_f32):
+//   one workgroup = 256 threads = 4 waves (one per SIMD), tile = 64 points x 512 channels.
+//   Wave w owns output channels [128w,128w+128): 2 (point tiles) x 4 (channel tiles)
+//   accumulators of 32x32 -> the residual stream lives in 128 accumulator registers and
+//   never leaves the register file; the activation that feeds the next GEMM goes through
+//   one LDS buffer X[64][516] (row stride 516 floats: conflict-free ds_read_b128 A-fragments).
+//   Weights are pre-packed fragment-major (common.h) and streamed from L2/MALL with one
+//   fully coalesced 16-byte load per lane per 4 MFMAs.
+//   Algorithmic work: 5 308 416 FLOP per forward point, x3 for a gradient point.
+#include "common.h"
+#include "points.h"
+#include <string.h>
+
+namespace surfd {
+
+constexpr int H = 512;        // hidden width
+constexpr int NB = 5;         // residual blocks
+constexpr int NCBN = 2 * NB + 1;
+constexpr int TP = 64;        // points per tile
+constexpr int XS = H + 4;     // LDS row stride of X
+constexpr int ES = 68;        // LDS row stride of the 64-wide encoding / its adjoint
+constexpr int KG_H = H / 8;   // k-groups of a 512-deep contraction
+constexpr int KG_E = 8;       // k-groups of the 64-deep (63 + pad) first layer
+
+// private weight arena (floats): all MFMA-packed matrices in one buffer, all vectors in another,
+// so that every kernel-side address is one base pointer + a compile-time offset
+constexpr size_t SZ_FCP = (size_t)16 * KG_E * 256;     // packed fc_p       [16][8][64][4]
+constexpr size_t SZ_HH = (size_t)16 * KG_H * 256;      // packed 512x512    [16][64][64][4]
+constexpr size_t SZ_FCPT = (size_t)2 * KG_H * 256;     // packed fc_p^T     [2][64][64][4]
+constexpr size_t OFF_FCP = 0;
+__host__ __device__ constexpr size_t off_fc(int k, int which) { return SZ_FCP + (size_t)(2 * k + which) * SZ_HH; }
+__host__ __device__ constexpr size_t off_fcT(int k, int which) { return SZ_FCP + (size_t)(2 * NB + 2 * k + which) * SZ_HH; }
+constexpr size_t OFF_FCPT = SZ_FCP + (size_t)4 * NB * SZ_HH;
+constexpr size_t WPACK_FLOATS = OFF_FCPT + SZ_FCPT;
+constexpr int VOFF_BFCP = 0;
+__host__ __device__ constexpr int voff_bfc(int k, int which) { return H * (1 + 2 * k + which); }
+constexpr int VOFF_WOUT = H * (1 + 2 * NB);
+constexpr int VOFF_BOUT = H * (2 + 2 * NB);
+constexpr int VEC_FLOATS = VOFF_BOUT + 4;
+
+struct DecParams {
+    const float *wpack;   // WPACK_FLOATS
+    const float *vecs;    // VEC_FLOATS: biases, w_out, b_out
+    const float *tab;     // this sample's [NCBN][2][H] scale/shift
+    int input_dim;
+};
+
+typedef float __attribute__((address_space(1))) gfloat;
+typedef f32x4 __attribute__((address_space(1))) gf32x4;
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// acc[mt][nt] += A[64 x 8*KG] (LDS, row stride astride) * Wp(4 channel tiles of this wave)
+// Software pipeline: weight fragments of k-group kg+1 are requested before the 32 MFMAs of
+// k-group kg are issued (ping-pong register sets, no copies), so one k-group of MFMA time
+// (2048 cycles) covers the L2/MALL latency.
+__device__ __forceinline__ void mfma_group(const f32x4 &x0, const f32x4 &x1, const f32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[0][nt] = mfma(x0[q], b[nt][q], acc[0][nt]);
+            acc[1][nt] = mfma(x1[q], b[nt][q], acc[1][nt]);
+        }
+    }
+}
+
+template <int KG>
+__device__ __forceinline__ void gemm_2x4(const float *A, int astride, const gfloat *Wp, f32x16 (&acc)[2][4], int lane) {
+    static_assert(KG % 2 == 0, "k-group count must be even");
+    const float *a0 = A + (lane & 31) * astride + 4 * (lane >> 5);
+    const float *a1 = a0 + 32 * astride;
+    const gf32x4 *w = reinterpret_cast<const gf32x4 *>(Wp) + lane;
+    f32x4 bA[4], bB[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bA[nt] = w[(nt * KG) * 64];
+    f32x4 xa0 = *reinterpret_cast<const f32x4 *>(a0), xa1 = *reinterpret_cast<const f32x4 *>(a1);
+#pragma unroll 1
+    for (int kg = 0; kg < KG; kg += 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bB[nt] = w[(nt * KG + kg + 1) * 64];
+        const f32x4 xb0 = *reinterpret_cast<const f32x4 *>(a0 + (kg + 1) * 8);
+        const f32x4 xb1 = *reinterpret_cast<const f32x4 *>(a1 + (kg + 1) * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(xa0, xa1, bA, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bA[nt] = w[(nt * KG + k2) * 64];
+        xa0 = *reinterpret_cast<const f32x4 *>(a0 + k2 * 8);
+        xa1 = *reinterpret_cast<const f32x4 *>(a1 + k2 * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(xb0, xb1, bB, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one 32x32 tile: rows = points [32*mt, +32), cols = packed tile `Wp_tile`
+template <int KG>
+__device__ __forceinline__ void gemm_1x1(const float *A, int astride, int mt, const gfloat *Wp_tile, f32x16 &acc, int lane) {
+    const float *a0 = A + (32 * mt + (lane & 31)) * astride + 4 * (lane >> 5);
+    const gf32x4 *w = reinterpret_cast<const gf32x4 *>(Wp_tile) + lane;
+#pragma unroll 4
+    for (int kg = 0; kg < KG; ++kg) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(a0 + kg * 8);
+        const f32x4 b = w[kg * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = mfma(x0[q], b[q], acc);
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+}
+
+// bit position of accumulator element (mt, nt, r) in a lane's 128-bit ReLU mask
+__device__ __forceinline__ constexpr int mword(int mt, int nt) { return (mt * 4 + nt) >> 1; }
+__device__ __forceinline__ constexpr int mbit(int mt, int nt, int r) { return ((mt * 4 + nt) & 1) * 16 + r; }
+
+template <bool GRAD>
+__global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *X = lds;                      // [TP][XS]
+    float *E = lds;                      // [TP][ES] first-layer input, aliases X (dead before X is written)
+    float *PT = lds + TP * XS;           // [TP][4]: x, y, z, voxel index bits
+    float *LOG = PT + TP * 4;            // [TP]
+    float *E2 = LOG + TP;                // [TP][ES] d logit / d enc          (GRAD only)
+    float *DV = E2 + TP * ES;            // [TP][4]  d logit / d xyz          (GRAD only)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31;
+    const long npts = pt_count(io);
+    const long ntiles = (npts + TP - 1) / TP;
+    // per-lane LDS bases of this wave's accumulator footprint in X (one per point tile): every
+    // element (mt, nt, r) is then base + compile-time offset (< 64 KB, fits the ds immediate)
+    float *const xb0 = X + (4 * (lane >> 5)) * XS + 128 * wave + col;
+    float *const xb1 = xb0 + 32 * XS;
+#define XAT(mt, nt, r) ((mt) ? xb1 : xb0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (nt)]
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long e0 = tile * TP;
+        // re-materialise the arena bases per tile: keeps the compiler from hoisting ~100 derived
+        // 64-bit layer addresses out of the tile loop and spilling them to scratch
+        const float *wpack_ = P.wpack, *vecs_ = P.vecs, *tab_ = P.tab;
+        asm volatile("" : "+s"(wpack_), "+s"(vecs_), "+s"(tab_));
+        // (the asm erases the address space: restore "global" so loads stay global_load, not flat)
+        const gfloat *wpack = (const gfloat *)wpack_, *vecs = (const gfloat *)vecs_, *tab = (const gfloat *)tab_;
+        __syncthreads();   // previous tile's readers of PT/LOG/E2/DV are done
+        // ---- 1. fetch points ------------------------------------------------------------
+        if (tid < TP) {
+            const long e = e0 + tid;
+            float x = 0.f, y = 0.f, z = 0.f;
+            int vox = -1;
+            if (e < npts) {
+                if (io.mode == PT_XYZ) {
+                    x = io.xyz[e * 3 + 0]; y = io.xyz[e * 3 + 1]; z = io.xyz[e * 3 + 2];
+                    vox = 0;
+                } else if (io.mode == PT_EMB) {
+                    vox = 0;
+                } else {
+                    vox = pt_voxel(io, e);
+                    voxel_xyz(io, vox, x, y, z);
+                }
+            }
+            PT[tid * 4 + 0] = x; PT[tid * 4 + 1] = y; PT[tid * 4 + 2] = z;
+            PT[tid * 4 + 3] = __int_as_float(vox);
+        }
+        __syncthreads();
+        // ---- 2. positional encoding into E[p][0..63] ---------------------------------------
+        {
+            const int p = tid >> 2, part = tid & 3;
+            if (io.mode == PT_EMB) {
+                const long e = e0 + p;
+#pragma unroll 4
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = part * 16 + jj;
+                    E[p * ES + j] = (e < npts && j < io.emb_dim) ? io.xyz[e * io.emb_dim + j] : 0.f;
+                }
+            } else {
+                const float c3[3] = {PT[p * 4 + 0], PT[p * 4 + 1], PT[p * 4 + 2]};
+#pragma unroll 4
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = part * 16 + jj;
+                    float v;
+                    if (j < 3) v = c3[j];
+                    else if (j == 63) v = 0.f;
+                    else {
+                        const int f = (j - 3) / 6, r = (j - 3) % 6;
+                        const float a = c3[r % 3] * (float)(1 << f);      // exact: power-of-two scale
+                        v = (r < 3) ? sinf(a) : cosf(a);
+                    }
+                    E[p * ES + j] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. fc_p -----------------------------------------------------------------------
+        f32x16 net[2][4], tmp[2][4];
+        unsigned msk[GRAD ? NCBN : 1][4];
+        zero_acc(net);
+        gemm_2x4<KG_E>(E, ES, wpack + OFF_FCP + (size_t)(4 * wave) * KG_E * 256, net, lane);
+        {
+            float bias[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bias[nt] = vecs[VOFF_BFCP + 32 * (4 * wave + nt) + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) net[mt][nt][r] += bias[nt];
+        }
+        __syncthreads();   // E (aliasing X) fully consumed
+        // ---- 4. residual blocks ---------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            // X <- relu(a*net + b), layer 2k
+            {
+                float sa[4], sb[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int c = 32 * (4 * wave + nt) + col;
+                    sa[nt] = tab[(2 * k) * 2 * H + c];
+                    sb[nt] = tab[(2 * k) * 2 * H + H + c];
+                }
+                if constexpr (GRAD) { msk[2 * k][0] = msk[2 * k][1] = msk[2 * k][2] = msk[2 * k][3] = 0u; }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float u = sa[nt] * net[mt][nt][r] + sb[nt];
+                            if constexpr (GRAD) if (u > 0.f) msk[2 * k][mword(mt, nt)] |= 1u << mbit(mt, nt, r);
+                            XAT(mt, nt, r) = fmaxf(u, 0.f);
+                        }
+            }
+            __syncthreads();
+            zero_acc(tmp);
+            gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 0) + (size_t)(4 * wave) * KG_H * 256, tmp, lane);
+            __syncthreads();
+            // X <- relu(a*(tmp + bias0) + b), layer 2k+1
+            {
+                float sa[4], sb[4], bias[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int c = 32 * (4 * wave + nt) + col;
+                    sa[nt] = tab[(2 * k + 1) * 2 * H + c];
+                    sb[nt] = tab[(2 * k + 1) * 2 * H + H + c];
+                    bias[nt] = vecs[voff_bfc(k, 0) + c];
+                }
+                if constexpr (GRAD) { msk[2 * k + 1][0] = msk[2 * k + 1][1] = msk[2 * k + 1][2] = msk[2 * k + 1][3] = 0u; }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float u = sa[nt] * (tmp[mt][nt][r] + bias[nt]) + sb[nt];
+                            if constexpr (GRAD) if (u > 0.f) msk[2 * k + 1][mword(mt, nt)] |= 1u << mbit(mt, nt, r);
+                            XAT(mt, nt, r) = fmaxf(u, 0.f);
+                        }
+            }
+            __syncthreads();
+            // net += fc_1(X) + bias1   (residual accumulates straight into the MFMA C operand)
+            gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 1) + (size_t)(4 * wave) * KG_H * 256, net, lane);
+            {
+                float bias[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bias[nt] = vecs[voff_bfc(k, 1) + 32 * (4 * wave + nt) + col];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) net[mt][nt][r] += bias[nt];
+            }
+            __syncthreads();
+        }
+        // ---- 5. final CBN + ReLU + fc_out (512 -> 1) -----------------------------------------
+        float wo[4], a10[4];
+        {
+            float sb[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int c = 32 * (4 * wave + nt) + col;
+                a10[nt] = tab[(2 * NB) * 2 * H + c];
+                sb[nt] = tab[(2 * NB) * 2 * H + H + c];
+                wo[nt] = vecs[VOFF_WOUT + c];
+            }
+            if constexpr (GRAD) { msk[2 * NB][0] = msk[2 * NB][1] = msk[2 * NB][2] = msk[2 * NB][3] = 0u; }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float u = a10[nt] * net[mt][nt][r] + sb[nt];
+                        if constexpr (GRAD) if (u > 0.f) msk[2 * NB][mword(mt, nt)] |= 1u << mbit(mt, nt, r);
+                        XAT(mt, nt, r) = fmaxf(u, 0.f) * wo[nt];
+                    }
+        }
+        __syncthreads();
+        {
+            const float bo = vecs[VOFF_BOUT];
+            for (int pp = 0; pp < TP / 4; ++pp) {
+                const int p = wave * (TP / 4) + pp;
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < H / 64; ++i) sacc += X[p * XS + lane + 64 * i];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+                if (lane == 0) LOG[p] = sacc + bo;
+            }
+        }
+        __syncthreads();
+
+        if constexpr (!GRAD) {
+            if (tid < TP) {
+                const long e = e0 + tid;
+                if (e < npts) {
+                    const float o = LOG[tid];
+                    const float y = 1.f / (1.f + expf(-o));
+                    const float udf = (1.f - y) * 0.1f;
+                    if (io.out_logit) io.out_logit[e] = o;
+                    if (io.out_udf) io.out_udf[e] = udf;
+                    if (io.grid_udf) {
+                        const int vox = __float_as_int(PT[tid * 4 + 3]);
+                        io.grid_udf[vox] = udf;
+                        if (io.grad_list && udf < io.grad_thr) io.grad_list[atomicAdd(io.grad_count, 1)] = vox;
+                    }
+                }
+            }
+        }
+
+        if constexpr (GRAD) {
+            // ---- 6. reverse sweep: g = d logit / d net, kept in the accumulator layout ----------
+            f32x16 (&g)[2][4] = net;   // net is dead from here on
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        g[mt][nt][r] = ((msk[2 * NB][mword(mt, nt)] >> mbit(mt, nt, r)) & 1u) ? wo[nt] * a10[nt] : 0.f;
+#pragma unroll
+            for (int k = NB - 1; k >= 0; --k) {
+                // X <- g
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            XAT(mt, nt, r) = g[mt][nt][r];
+                __syncthreads();
+                zero_acc(tmp);
+                gemm_2x4<KG_H>(X, XS, wpack + off_fcT(k, 1) + (size_t)(4 * wave) * KG_H * 256, tmp, lane);   // t = fc_1^T g
+                __syncthreads();
+                {
+                    float sa[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) sa[nt] = tab[(2 * k + 1) * 2 * H + 32 * (4 * wave + nt) + col];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const bool on = (msk[2 * k + 1][mword(mt, nt)] >> mbit(mt, nt, r)) & 1u;
+                                XAT(mt, nt, r) = on ? tmp[mt][nt][r] * sa[nt] : 0.f;
+                            }
+                }
+                __syncthreads();
+                zero_acc(tmp);
+                gemm_2x4<KG_H>(X, XS, wpack + off_fcT(k, 0) + (size_t)(4 * wave) * KG_H * 256, tmp, lane);   // fc_0^T t
+                {
+                    float sa[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) sa[nt] = tab[(2 * k) * 2 * H + 32 * (4 * wave + nt) + col];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const bool on = (msk[2 * k][mword(mt, nt)] >> mbit(mt, nt, r)) & 1u;
+                                g[mt][nt][r] += on ? tmp[mt][nt][r] * sa[nt] : 0.f;
+                            }
+                }
+                __syncthreads();
+            }
+            // X <- g ; e2 = fc_p^T g  (64 x 64)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        XAT(mt, nt, r) = g[mt][nt][r];
+            __syncthreads();
+            {
+                f32x16 ea;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ea[r] = 0.f;
+                const int mt = wave & 1, et = wave >> 1;
+                gemm_1x1<KG_H>(X, XS, mt, wpack + OFF_FCPT + (size_t)et * KG_H * 256, ea, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) E2[(32 * mt + frag_row(r, lane)) * ES + 32 * et + col] = ea[r];
+            }
+            __syncthreads();
+            if (tid < TP * 3) {
+                const int p = tid / 3, c = tid % 3;
+                const float xc = PT[p * 4 + c];
+                float d = E2[p * ES + c];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const float f = (float)(1 << j);
+                    float sn, cs;
+                    sincosf(xc * f, &sn, &cs);
+                    d += f * (cs * E2[p * ES + 3 + 6 * j + c] - sn * E2[p * ES + 6 + 6 * j + c]);
+                }
+                DV[p * 4 + c] = d;
+            }
+            __syncthreads();
+            if (tid < TP) {
+                const long e = e0 + tid;
+                if (e < npts) {
+                    const float o = LOG[tid];
+                    const float y = 1.f / (1.f + expf(-o));
+                    const float udf = (1.f - y) * 0.1f;
+                    const float sfac = -0.1f * ((1.f - y) * y);   // d udf / d logit as torch's sigmoid backward forms it
+                    const float gx = sfac * DV[tid * 4 + 0], gy = sfac * DV[tid * 4 + 1], gz = sfac * DV[tid * 4 + 2];
+                    const float nrm = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+                    const float ox = -(gx / nrm), oy = -(gy / nrm), oz = -(gz / nrm);
+                    if (io.out_logit) io.out_logit[e] = o;
+                    if (io.out_udf) io.out_udf[e] = udf;
+                    if (io.out_ngrad) { io.out_ngrad[e * 3 + 0] = ox; io.out_ngrad[e * 3 + 1] = oy; io.out_ngrad[e * 3 + 2] = oz; }
+                    if (io.grid_grads) {
+                        const long vox = __float_as_int(PT[tid * 4 + 3]);
+                        io.grid_grads[vox * 3 + 0] = ox; io.grid_grads[vox * 3 + 1] = oy; io.grid_grads[vox * 3 + 2] = oz;
+                    }
+                }
+            }
+        }
+    }
+}
+
+#undef XAT
+constexpr size_t DEC_LDS_BYTES = (size_t)(TP * XS + TP * 4 + TP + TP * ES + TP * 4) * sizeof(float);
+
+// ---------------------------------------------------------------------------------------------
+// per-sample conditional-BN tables
+// ---------------------------------------------------------------------------------------------
+struct CbnParams {
+    const float *gw[NCBN], *gb[NCBN], *bw[NCBN], *bb[NCBN], *mean[NCBN], *var[NCBN];
+};
+
+__global__ void cbn_table_kernel(CbnParams P, const float *lat, int S, int D, float *tab) {
+    const int total = S * NCBN * H;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int c = e % H, l = (e / H) % NCBN, s = e / (H * NCBN);
+        float gamma = 0.f, beta = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float z = lat[s * D + d];
+            gamma += P.gw[l][c * D + d] * z;
+            beta += P.bw[l][c * D + d] * z;
+        }
+        gamma += P.gb[l][c];
+        beta += P.bb[l][c];
+        const float a = gamma / sqrtf(P.var[l][c] + 1e-5f);
+        tab[((size_t)(s * NCBN + l) * 2 + 0) * H + c] = a;
+        tab[((size_t)(s * NCBN + l) * 2 + 1) * H + c] = beta - a * P.mean[l][c];
+    }
+}
+
+}  // namespace surfd
+
+// =============================================================================================
+// host side
+// =============================================================================================
+using namespace surfd;
+
+struct DecTensor {
+    std::string key;
+    std::vector<int64_t> shape;
+    bool is_set = false;
+};
+
+struct surfd_decoder {
+    int input_dim = 63, D = 32, hidden = 512, nb = 5, device = -1;
+    std::vector<DecTensor> params;
+    std::map<std::string, int> index;
+    bool allocated = false, finalized = false;
+    // private device copies
+    float *wpack = nullptr, *vecs = nullptr;
+    float *gw[NCBN] = {}, *gb[NCBN] = {}, *bw[NCBN] = {}, *bb[NCBN] = {}, *mean[NCBN] = {}, *var[NCBN] = {};
+    float *tab = nullptr;
+    int S = 0, tab_cap = 0;
+    int num_cus = 256;
+    std::vector<void *> allocs;
+};
+
+static void dec_add(surfd_decoder *d, const std::string &k, std::vector<int64_t> shape) {
+    d->index[k] = (int)d->params.size();
+    d->params.push_back({k, std::move(shape)});
+}
+
+static void dec_add_cbn(surfd_decoder *d, const std::string &p) {
+    const int64_t Hh = d->hidden, D = d->D;
+    dec_add(d, p + ".conv_gamma.weight", {Hh, D, 1}); dec_add(d, p + ".conv_gamma.bias", {Hh});
+    dec_add(d, p + ".conv_beta.weight", {Hh, D, 1});  dec_add(d, p + ".conv_beta.bias", {Hh});
+    dec_add(d, p + ".bn.running_mean", {Hh});         dec_add(d, p + ".bn.running_var", {Hh});
+    dec_add(d, p + ".bn.num_batches_tracked", {});
+}
+
+static int dec_alloc(surfd_decoder *d) {
+    if (d->allocated) return SURFD_OK;
+    HIP_TRY(hipGetDevice(&d->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+    d->num_cus = prop.multiProcessorCount;
+    auto A = [&](float **p, size_t n) -> int {
+        HIP_TRY(hipMalloc((void **)p, n * sizeof(float)));
+        d->allocs.push_back(*p);
+        return SURFD_OK;
+    };
+    int rc;
+    if ((rc = A(&d->wpack, WPACK_FLOATS))) return rc;
+    if ((rc = A(&d->vecs, VEC_FLOATS))) return rc;
+    for (int l = 0; l < NCBN; ++l) {
+        if ((rc = A(&d->gw[l], (size_t)H * d->D))) return rc;
+        if ((rc = A(&d->bw[l], (size_t)H * d->D))) return rc;
+        if ((rc = A(&d->gb[l], H))) return rc;
+        if ((rc = A(&d->bb[l], H))) return rc;
+        if ((rc = A(&d->mean[l], H))) return rc;
+        if ((rc = A(&d->var[l], H))) return rc;
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
+    d->allocated = true;
+    return SURFD_OK;
+}
+
+static int pack_matrix(const float *src, int N, int K, bool transpose, float *dst, hipStream_t s) {
+    // logical W[n][k]; source is row-major [N][K] (or [K][N] when transpose: W^T)
+    PackDesc pd;
+    pd.src = src; pd.dst = dst;
+    pd.N = N; pd.K = K;
+    pd.Npad = ceil_div(N, 32) * 32; pd.Kpad = ceil_div(K, 8) * 8;
+    pd.inner = pd.Kpad; pd.inner_valid = K; pd.os = 0;
+    if (!transpose) { pd.rs = K; pd.is = 1; }
+    else { pd.rs = 1; pd.is = N; }
+    pd.KGtot = pd.Kpad / 8; pd.kg_off = 0;
+    return launch_pack(pd, s);
+}
+
+extern "C" {
+
+int surfd_decoder_create(int input_dim, int latent_dim, int hidden_dim, int num_blocks, surfd_decoder **out) {
+    if (!out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_create: out is null");
+    if (hidden_dim != H || num_blocks != NB || input_dim < 1 || input_dim > 63 || latent_dim < 1)
+        SURFD_FAIL(SURFD_ERR_UNSUPPORTED,
+                   "surfd_decoder_create: kernels are built for CbnDecoder(<=63, D, 512, 5); got (%d, %d, %d, %d)",
+                   input_dim, latent_dim, hidden_dim, num_blocks);
+    auto *d = new surfd_decoder();
+    d->input_dim = input_dim; d->D = latent_dim; d->hidden = hidden_dim; d->nb = num_blocks;
+    dec_add(d, "decoder.fc_p.weight", {H, input_dim, 1});
+    dec_add(d, "decoder.fc_p.bias", {H});
+    for (int k = 0; k < NB; ++k) {
+        const std::string b = "decoder.blocks." + std::to_string(k);
+        dec_add_cbn(d, b + ".bn_0");
+        dec_add_cbn(d, b + ".bn_1");
+        dec_add(d, b + ".fc_0.weight", {H, H, 1}); dec_add(d, b + ".fc_0.bias", {H});
+        dec_add(d, b + ".fc_1.weight", {H, H, 1}); dec_add(d, b + ".fc_1.bias", {H});
+    }
+    dec_add_cbn(d, "decoder.bn");
+    dec_add(d, "decoder.fc_out.weight", {1, H, 1});
+    dec_add(d, "decoder.fc_out.bias", {1});
+    *out = d;
+    return SURFD_OK;
+}
+
+void surfd_decoder_destroy(surfd_decoder *d) {
+    if (!d) return;
+    for (void *p : d->allocs) (void)hipFree(p);
+    if (d->tab) (void)hipFree(d->tab);
+    delete d;
+}
+
+int surfd_decoder_num_params(const surfd_decoder *d) { return d ? (int)d->params.size() : 0; }
+
+int surfd_decoder_param_info(const surfd_decoder *d, int i, const char **key, int64_t shape[4], int *ndim) {
+    if (!d || i < 0 || i >= (int)d->params.size()) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_param_info: bad index %d", i);
+    *key = d->params[i].key.c_str();
+    *ndim = (int)d->params[i].shape.size();
+    for (int j = 0; j < *ndim; ++j) shape[j] = d->params[i].shape[j];
+    return SURFD_OK;
+}
+
+int surfd_decoder_set_param(surfd_decoder *d, const char *key, const void *dev_ptr, const int64_t *shape, int ndim,
+                            surfd_stream s) {
+    if (!d || !key) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_param: null argument");
+    auto it = d->index.find(key);
+    if (it == d->index.end()) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_param: unexpected key '%s'", key);
+    DecTensor &t = d->params[it->second];
+    if (ndim != (int)t.shape.size()) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_param: '%s' rank %d, expected %zu", key, ndim, t.shape.size());
+    size_t numel = 1;
+    for (int j = 0; j < ndim; ++j) {
+        if (shape[j] != t.shape[j]) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_param: '%s' dim %d is %lld, expected %lld", key, j, (long long)shape[j], (long long)t.shape[j]);
+        numel *= shape[j];
+    }
+    const std::string k(key);
+    if (k.size() > 19 && k.rfind("num_batches_tracked") == k.size() - 19) { t.is_set = true; return SURFD_OK; }
+    if (!dev_ptr) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_param: '%s' has a null pointer", key);
+    int rc = dec_alloc(d);
+    if (rc) return rc;
+    hipStream_t st = as_stream(s);
+    const float *src = static_cast<const float *>(dev_ptr);
+    auto copy = [&](float *dst) -> int {
+        HIP_TRY(hipMemcpyAsync(dst, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return SURFD_OK;
+    };
+    // which CBN layer / block does the key belong to?
+    auto cbn_index = [&](const std::string &kk) -> int {
+        if (kk.rfind("decoder.bn.", 0) == 0) return 2 * NB;
+        int blk = -1, which = -1;
+        if (sscanf(kk.c_str(), "decoder.blocks.%d.bn_%d.", &blk, &which) == 2) return 2 * blk + which;
+        return -1;
+    };
+    if (k == "decoder.fc_p.weight") {
+        if ((rc = pack_matrix(src, H, d->input_dim, false, d->wpack + OFF_FCP, st))) return rc;
+        // adjoint: rows = encoding index (padded to 64), k = hidden
+        PackDesc pd;
+        pd.src = src; pd.dst = d->wpack + OFF_FCPT; pd.N = d->input_dim; pd.K = H; pd.Npad = 64; pd.Kpad = H;
+        pd.inner = H; pd.inner_valid = H; pd.os = 0; pd.rs = 1; pd.is = d->input_dim; pd.KGtot = KG_H; pd.kg_off = 0;
+        rc = launch_pack(pd, st);
+    } else if (k == "decoder.fc_p.bias") rc = copy(d->vecs + VOFF_BFCP);
+    else if (k == "decoder.fc_out.weight") rc = copy(d->vecs + VOFF_WOUT);
+    else if (k == "decoder.fc_out.bias") rc = copy(d->vecs + VOFF_BOUT);
+    else if (k.find(".conv_gamma.weight") != std::string::npos) rc = copy(d->gw[cbn_index(k)]);
+    else if (k.find(".conv_gamma.bias") != std::string::npos) rc = copy(d->gb[cbn_index(k)]);
+    else if (k.find(".conv_beta.weight") != std::string::npos) rc = copy(d->bw[cbn_index(k)]);
+    else if (k.find(".conv_beta.bias") != std::string::npos) rc = copy(d->bb[cbn_index(k)]);
+    else if (k.find(".running_mean") != std::string::npos) rc = copy(d->mean[cbn_index(k)]);
+    else if (k.find(".running_var") != std::string::npos) rc = copy(d->var[cbn_index(k)]);
+    else {
+        int blk = -1, which = -1;
+        char leaf[16] = "";
+        if (sscanf(k.c_str(), "decoder.blocks.%d.fc_%d.%15s", &blk, &which, leaf) != 3 || blk < 0 || blk >= NB)
+            SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_param: cannot place key '%s'", key);
+        if (!strcmp(leaf, "bias")) rc = copy(d->vecs + voff_bfc(blk, which ? 1 : 0));
+        else {
+            if ((rc = pack_matrix(src, H, H, false, d->wpack + off_fc(blk, which ? 1 : 0), st))) return rc;
+            rc = pack_matrix(src, H, H, true, d->wpack + off_fcT(blk, which ? 1 : 0), st);
+        }
+    }
+    if (rc) return rc;
+    t.is_set = true;
+    d->finalized = false;
+    return SURFD_OK;
+}
+
+int surfd_decoder_finalize(surfd_decoder *d, surfd_stream) {
+    if (!d) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_finalize: null handle");
+    for (auto &t : d->params)
+        if (!t.is_set) SURFD_FAIL(SURFD_ERR_STATE, "surfd_decoder_finalize: parameter '%s' was never set", t.key.c_str());
+    d->finalized = true;
+    return SURFD_OK;
+}
+
+int surfd_decoder_bind_latents(surfd_decoder *d, const float *lat, int S, surfd_stream s) {
+    if (!d || !lat || S < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_bind_latents: bad argument");
+    if (!d->finalized) SURFD_FAIL(SURFD_ERR_STATE, "surfd_decoder_bind_latents: call surfd_decoder_finalize first");
+    if (S > d->tab_cap) {
+        if (d->tab) HIP_TRY(hipFree(d->tab));
+        d->tab = nullptr;
+        HIP_TRY(hipMalloc((void **)&d->tab, (size_t)S * NCBN * 2 * H * sizeof(float)));
+        d->tab_cap = S;
+    }
+    CbnParams P;
+    for (int l = 0; l < NCBN; ++l) {
+        P.gw[l] = d->gw[l]; P.gb[l] = d->gb[l]; P.bw[l] = d->bw[l]; P.bb[l] = d->bb[l];
+        P.mean[l] = d->mean[l]; P.var[l] = d->var[l];
+    }
+    const int total = S * NCBN * H;
+    hipLaunchKernelGGL(cbn_table_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(s), P, lat, S, d->D, d->tab);
+    LAUNCH_CHECK();
+    d->S = S;
+    return SURFD_OK;
+}
+
+}  // extern "C"
+
+namespace surfd {
+
+// Enqueue the decoder over a point source; used by the C entry points below and by grid.hip.
+int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles_hint, hipStream_t st) {
+    if (!d) SURFD_FAIL(SURFD_ERR_ARG, "decoder: null handle");
+    if (!d->finalized) SURFD_FAIL(SURFD_ERR_STATE, "decoder: parameters not finalized");
+    if (sample < 0 || sample >= d->S) SURFD_FAIL(SURFD_ERR_STATE, "decoder: sample %d not bound (%d latents bound)", sample, d->S);
+    DecParams P;
+    P.wpack = d->wpack; P.vecs = d->vecs;
+    P.tab = d->tab + (size_t)sample * NCBN * 2 * H;
+    P.input_dim = d->input_dim;
+    io.emb_dim = d->input_dim;
+    // one workgroup per CU (LDS-limited); a device-side count is handled by the tile loop
+    long blocks = d->num_cus;
+    if (ntiles_hint >= 0) blocks = std::min<long>(blocks, std::max<long>(ntiles_hint, 1));
+    if (grad)
+        hipLaunchKernelGGL(decoder_kernel<true>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
+    else
+        hipLaunchKernelGGL(decoder_kernel<false>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+}  // namespace surfd
+
+extern "C" {
+
+static PtIO make_io(int mode, const float *src, int64_t n) {
+    PtIO io;
+    memset(&io, 0, sizeof(io));
+    io.mode = mode; io.xyz = src; io.n = n;
+    return io;
+}
+
+int surfd_decoder_logits_emb(surfd_decoder *d, int sample, const float *emb, int64_t n, float *logits, surfd_stream s) {
+    if (!emb || !logits || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_logits_emb: bad argument");
+    if (n == 0) return SURFD_OK;
+    PtIO io = make_io(PT_EMB, emb, n);
+    io.out_logit = logits;
+    return decoder_launch(d, sample, io, false, ceil_div<long>(n, TP), as_stream(s));
+}
+
+int surfd_decoder_udf(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf, float *logits, surfd_stream s) {
+    if (!pts || (!udf && !logits) || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf: bad argument");
+    if (n == 0) return SURFD_OK;
+    PtIO io = make_io(PT_XYZ, pts, n);
+    io.out_udf = udf; io.out_logit = logits;
+    return decoder_launch(d, sample, io, false, ceil_div<long>(n, TP), as_stream(s));
+}
+
+int surfd_decoder_udf_grad(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf, float *ngrad, surfd_stream s) {
+    if (!pts || !ngrad || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf_grad: bad argument");
+    if (n == 0) return SURFD_OK;
+    PtIO io = make_io(PT_XYZ, pts, n);
+    io.out_udf = udf; io.out_ngrad = ngrad;
+    return decoder_launch(d, sample, io, true, ceil_div<long>(n, TP), as_stream(s));
+}
+
+}  // extern "C"

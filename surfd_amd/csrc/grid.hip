@@ -1,0 +1,359 @@
+// Coarse-to-fine UDF grid filling on the device (HBM-bound index/byte work; the decoder
+// evaluations it schedules are the MFMA-bound part, decoder.hip).
+//
+// Replaces GridFiller.__init__/fill_grid and get_udf_and_grads (reference
+// meshudf/meshudf.py:36-206, 254-304).  The reference materialises, per sample, a
+// samples[N^3,7] table, N^3 boolean masks per level and int64 [N^3/b, b] block-index tensors
+// (about 1 GiB per level at 512^3).  Here every level is a compacted list of *active block
+// corners* (int32 voxel indices); everything else is index arithmetic:
+//
+//   level l (lattice stride s_l = N / n_l), parents[l] = corners of the level l-1 blocks whose
+//   corner value was "close" (|udf| < 1.5*1.7*2/n_{l-1}):
+//     evaluate  : the 7 not-yet-evaluated children p + {0,1}^3 * s_l  (level 0: all 32^3)
+//     classify  : all 8 children; close -> parents[l+1]; far -> block [c, c+s_l)^3 := udf(c)
+//   gradients   : every evaluated voxel with udf < 2.5*2/N is appended to grad_list when its
+//                 value is written (pruned voxels hold values >= the refine threshold, which
+//                 always exceeds the gradient threshold, unless the field is negative — the
+//                 fill kernel covers that case too).
+// No host round trip is needed between levels: list lengths stay in device counters and the
+// consuming kernels size their loops from them.
+#include "common.h"
+#include "points.h"
+#include <string.h>
+
+namespace surfd {
+
+constexpr int CTR_PARENT = 0;                       // [0..7]   parents[l] length
+constexpr int CTR_FAR = SURFD_GRID_MAX_LEVELS;      // [8..15]  far blocks found at level l
+constexpr int CTR_GRAD = 2 * SURFD_GRID_MAX_LEVELS; // [16]     gradient points
+constexpr int CTR_TOTAL = CTR_GRAD + 1;
+
+__global__ void classify_kernel(PtIO io, const float *udf, float thr, int *close_list, int *close_count,
+                                int *far_list, int *far_count) {
+    const long n = pt_count(io);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int idx = pt_voxel(io, e);
+        const float v = udf[idx];
+        if (fabsf(v) < thr) close_list[atomicAdd(close_count, 1)] = idx;
+        else far_list[atomicAdd(far_count, 1)] = idx;
+    }
+}
+
+// every voxel of a pruned block takes the value of the block's corner
+__global__ void fill_kernel(const int *far_list, const int *far_count, int s, int log2s, int N, float *udf,
+                            float grad_thr, int *grad_list, int *grad_count) {
+    const long total = (long)(*far_count) << (3 * log2s);
+    const int mask = s - 1;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(e >> (3 * log2s));
+        const int w = (int)(e & ((1 << (3 * log2s)) - 1));
+        const int dk = w & mask, dj = (w >> log2s) & mask, di = w >> (2 * log2s);
+        const int p = far_list[b];
+        const float v = udf[p];
+        if (w != 0) {
+            const int q = p + di * N * N + dj * N + dk;
+            udf[q] = v;
+            // only reachable for fields that go negative: the reference's gradient mask is on
+            // the signed value (meshudf.py:200) while pruning is on |value| (:186)
+            if (grad_list && v < grad_thr) grad_list[atomicAdd(grad_count, 1)] = q;
+        }
+    }
+}
+
+__global__ void emit_points_kernel(PtIO io, float *xyz) {
+    const long n = pt_count(io);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        float x, y, z;
+        voxel_xyz(io, pt_voxel(io, e), x, y, z);
+        xyz[e * 3 + 0] = x; xyz[e * 3 + 1] = y; xyz[e * 3 + 2] = z;
+    }
+}
+
+__global__ void commit_kernel(PtIO io, const float *vals) {
+    const long n = pt_count(io);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int idx = pt_voxel(io, e);
+        const float v = vals[e];
+        io.grid_udf[idx] = v;
+        if (io.grad_list && v < io.grad_thr) io.grad_list[atomicAdd(io.grad_count, 1)] = idx;
+    }
+}
+
+__global__ void grad_commit_kernel(const int *list, long n, const float *ng, float *grads) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long idx = list[e];
+        grads[idx * 3 + 0] = ng[e * 3 + 0]; grads[idx * 3 + 1] = ng[e * 3 + 1]; grads[idx * 3 + 2] = ng[e * 3 + 2];
+    }
+}
+
+}  // namespace surfd
+
+using namespace surfd;
+
+struct surfd_grid {
+    int N = 0, n_levels = 0, levels[SURFD_GRID_MAX_LEVELS] = {};
+    float refine[SURFD_GRID_MAX_LEVELS] = {};
+    float grad_thr = 0.f, voxel = 0.f, origin = -1.f;
+    bool thresholds_set = false, allocated = false;
+    int *parents[SURFD_GRID_MAX_LEVELS] = {};
+    int *far_list = nullptr, *grad_list = nullptr, *counters = nullptr;
+    float *cur_udf = nullptr, *cur_grads = nullptr;   // callback path
+    bool dense_last = false;
+    long dense_n = 0;
+};
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+static int grid_alloc(surfd_grid *g) {
+    if (g->allocated) return SURFD_OK;
+    const long N3 = (long)g->N * g->N * g->N;
+    for (int l = 1; l < g->n_levels; ++l) {
+        const long cap = (long)g->levels[l - 1] * g->levels[l - 1] * g->levels[l - 1];
+        HIP_TRY(hipMalloc((void **)&g->parents[l], cap * sizeof(int)));
+    }
+    const int nl = g->n_levels;
+    const long far_cap = nl >= 2 ? (long)g->levels[nl - 2] * g->levels[nl - 2] * g->levels[nl - 2] : 1;
+    HIP_TRY(hipMalloc((void **)&g->far_list, far_cap * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&g->grad_list, N3 * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&g->counters, CTR_TOTAL * sizeof(int)));
+    HIP_TRY(hipMemset(g->counters, 0, CTR_TOTAL * sizeof(int)));
+    g->allocated = true;
+    return SURFD_OK;
+}
+
+static PtIO base_io(const surfd_grid *g) {
+    PtIO io;
+    memset(&io, 0, sizeof(io));
+    io.N = g->N; io.voxel = g->voxel; io.origin = g->origin; io.s = 1;
+    return io;
+}
+
+// enumeration of the points evaluated at `level`
+static PtIO eval_io(const surfd_grid *g, int level) {
+    PtIO io = base_io(g);
+    io.s = g->N / g->levels[level];
+    if (level == 0) {
+        io.mode = PT_LATTICE;
+        io.n = (long)g->levels[0] * g->levels[0] * g->levels[0];
+    } else {
+        io.mode = PT_CHILDREN;
+        io.list = g->parents[level];
+        io.count_dev = g->counters + CTR_PARENT + level;
+    }
+    return io;
+}
+
+// classification of all active lattice points of `level`, then pruned-block fill
+static int refine_level(surfd_grid *g, int level, float *udf, bool want_grads, hipStream_t st) {
+    if (g->levels[level] >= g->N) return SURFD_OK;
+    PtIO io = eval_io(g, level);
+    if (level > 0) io.mode = PT_CHILDREN8;
+    const int blocks = 1024;
+    hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, st, io, (const float *)udf, g->refine[level],
+                       g->parents[level + 1], g->counters + CTR_PARENT + level + 1, g->far_list,
+                       g->counters + CTR_FAR + level);
+    LAUNCH_CHECK();
+    const int s = g->N / g->levels[level];
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, (const int *)g->far_list,
+                       (const int *)(g->counters + CTR_FAR + level), s, ilog2(s), g->N, udf, g->grad_thr,
+                       want_grads ? g->grad_list : nullptr, g->counters + CTR_GRAD);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+static int check_ready(const surfd_grid *g, const char *fn) {
+    if (!g) SURFD_FAIL(SURFD_ERR_ARG, "%s: null handle", fn);
+    if (!g->thresholds_set) SURFD_FAIL(SURFD_ERR_STATE, "%s: call surfd_grid_set_thresholds first", fn);
+    return SURFD_OK;
+}
+
+extern "C" {
+
+int surfd_grid_create(int N, surfd_grid **out) {
+    if (!out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_create: out is null");
+    if (N < 64 || (N & (N - 1)) || N > 1024)
+        SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "surfd_grid_create: N must be a power of two in [64, 1024], got %d", N);
+    auto *g = new surfd_grid();
+    g->N = N;
+    // levels 32, 64, ..., N   (int(log2(N) - 4) of them, meshudf.py:46)
+    for (int n = 32; n <= N && g->n_levels < SURFD_GRID_MAX_LEVELS; n *= 2) g->levels[g->n_levels++] = n;
+    *out = g;
+    return SURFD_OK;
+}
+
+void surfd_grid_destroy(surfd_grid *g) {
+    if (!g) return;
+    for (int l = 0; l < SURFD_GRID_MAX_LEVELS; ++l)
+        if (g->parents[l]) (void)hipFree(g->parents[l]);
+    if (g->far_list) (void)hipFree(g->far_list);
+    if (g->grad_list) (void)hipFree(g->grad_list);
+    if (g->counters) (void)hipFree(g->counters);
+    delete g;
+}
+
+int surfd_grid_set_thresholds(surfd_grid *g, const float *refine, int n_levels, float grad_thr, float voxel, float origin) {
+    if (!g || !refine) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_set_thresholds: null argument");
+    if (n_levels != g->n_levels) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_set_thresholds: %d levels given, grid has %d", n_levels, g->n_levels);
+    for (int l = 0; l < n_levels; ++l) g->refine[l] = refine[l];
+    g->grad_thr = grad_thr; g->voxel = voxel; g->origin = origin;
+    g->thresholds_set = true;
+    return SURFD_OK;
+}
+
+int surfd_grid_fill(surfd_grid *g, surfd_decoder *d, int sample, float *udf, float *grads, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_fill");
+    if (rc) return rc;
+    if (!udf) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_fill: udf is null");
+    if ((rc = grid_alloc(g))) return rc;
+    hipStream_t st = as_stream(s);
+    const long N3 = (long)g->N * g->N * g->N;
+    HIP_TRY(hipMemsetAsync(g->counters, 0, CTR_TOTAL * sizeof(int), st));
+    if (grads) HIP_TRY(hipMemsetAsync(grads, 0, N3 * 3 * sizeof(float), st));
+    for (int l = 0; l < g->n_levels; ++l) {
+        PtIO io = eval_io(g, l);
+        io.grid_udf = udf;
+        if (grads) { io.grad_list = g->grad_list; io.grad_count = g->counters + CTR_GRAD; io.grad_thr = g->grad_thr; }
+        if ((rc = decoder_launch(d, sample, io, false, l == 0 ? ceil_div<long>(io.n, 64) : -1, st))) return rc;
+        if ((rc = refine_level(g, l, udf, grads != nullptr, st))) return rc;
+    }
+    if (grads) {
+        PtIO io = base_io(g);
+        io.mode = PT_LIST; io.list = g->grad_list; io.count_dev = g->counters + CTR_GRAD; io.grid_grads = grads;
+        if ((rc = decoder_launch(d, sample, io, true, -1, st))) return rc;
+    }
+    g->dense_last = false;
+    return SURFD_OK;
+}
+
+int surfd_grid_fill_dense(surfd_grid *g, surfd_decoder *d, int sample, float grad_below, float *udf, float *grads,
+                          surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_fill_dense");
+    if (rc) return rc;
+    if (!udf) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_fill_dense: udf is null");
+    if ((rc = grid_alloc(g))) return rc;
+    hipStream_t st = as_stream(s);
+    const long N3 = (long)g->N * g->N * g->N;
+    HIP_TRY(hipMemsetAsync(g->counters, 0, CTR_TOTAL * sizeof(int), st));
+    if (grads) HIP_TRY(hipMemsetAsync(grads, 0, N3 * 3 * sizeof(float), st));
+    PtIO io = base_io(g);
+    io.mode = PT_DENSE; io.n = N3; io.grid_udf = udf;
+    if (grads) { io.grad_list = g->grad_list; io.grad_count = g->counters + CTR_GRAD; io.grad_thr = grad_below; }
+    if ((rc = decoder_launch(d, sample, io, false, ceil_div<long>(N3, 64), st))) return rc;
+    if (grads) {
+        PtIO gi = base_io(g);
+        gi.mode = PT_LIST; gi.list = g->grad_list; gi.count_dev = g->counters + CTR_GRAD; gi.grid_grads = grads;
+        if ((rc = decoder_launch(d, sample, gi, true, -1, st))) return rc;
+    }
+    g->dense_last = true;
+    g->dense_n = N3;
+    return SURFD_OK;
+}
+
+int surfd_grid_get_stats(surfd_grid *g, surfd_grid_stats *out, surfd_stream s) {
+    if (!g || !out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_get_stats: null argument");
+    if (!g->allocated) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_get_stats: nothing has been filled yet");
+    int c[CTR_TOTAL];
+    HIP_TRY(hipMemcpyAsync(c, g->counters, sizeof(c), hipMemcpyDeviceToHost, as_stream(s)));
+    HIP_TRY(hipStreamSynchronize(as_stream(s)));
+    memset(out, 0, sizeof(*out));
+    out->n_levels = g->n_levels;
+    for (int l = 0; l < g->n_levels; ++l) {
+        out->levels[l] = g->levels[l];
+        out->fwd_points[l] = l == 0 ? (long)g->levels[0] * g->levels[0] * g->levels[0] : 7L * c[CTR_PARENT + l];
+    }
+    if (g->dense_last) {
+        for (int l = 0; l < g->n_levels; ++l) out->fwd_points[l] = 0;
+        out->fwd_points[g->n_levels - 1] = g->dense_n;
+    }
+    out->grad_points = c[CTR_GRAD];
+    return SURFD_OK;
+}
+
+// ---- callback path -------------------------------------------------------------------------
+int surfd_grid_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_begin");
+    if (rc) return rc;
+    if (!udf) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_begin: udf is null");
+    if ((rc = grid_alloc(g))) return rc;
+    hipStream_t st = as_stream(s);
+    const long N3 = (long)g->N * g->N * g->N;
+    HIP_TRY(hipMemsetAsync(g->counters, 0, CTR_TOTAL * sizeof(int), st));
+    if (grads) HIP_TRY(hipMemsetAsync(grads, 0, N3 * 3 * sizeof(float), st));
+    g->cur_udf = udf; g->cur_grads = grads; g->dense_last = false;
+    return SURFD_OK;
+}
+
+static int level_count(surfd_grid *g, int level, long *n, hipStream_t st) {
+    if (level == 0) { *n = (long)g->levels[0] * g->levels[0] * g->levels[0]; return SURFD_OK; }
+    int c = 0;
+    HIP_TRY(hipMemcpyAsync(&c, g->counters + CTR_PARENT + level, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n = 7L * c;
+    return SURFD_OK;
+}
+
+int surfd_grid_level_points(surfd_grid *g, int level, float *xyz, int64_t capacity, int64_t *n, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_level_points");
+    if (rc) return rc;
+    if (!g->cur_udf) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_level_points: call surfd_grid_begin first");
+    if (level < 0 || level >= g->n_levels || !n) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_level_points: bad level %d", level);
+    long cnt = 0;
+    if ((rc = level_count(g, level, &cnt, as_stream(s)))) return rc;
+    *n = cnt;
+    if (!xyz || cnt == 0) return SURFD_OK;
+    if (capacity < cnt) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_level_points: capacity %lld < %ld points", (long long)capacity, cnt);
+    PtIO io = eval_io(g, level);
+    hipLaunchKernelGGL(emit_points_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(cnt, 256), 4096)), dim3(256), 0,
+                       as_stream(s), io, xyz);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+int surfd_grid_level_commit(surfd_grid *g, int level, const float *values, int64_t n, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_level_commit");
+    if (rc) return rc;
+    if (!g->cur_udf) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_level_commit: call surfd_grid_begin first");
+    if (level < 0 || level >= g->n_levels) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_level_commit: bad level %d", level);
+    hipStream_t st = as_stream(s);
+    if (n > 0) {
+        if (!values) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_level_commit: values is null");
+        PtIO io = eval_io(g, level);
+        io.grid_udf = g->cur_udf;
+        if (g->cur_grads) { io.grad_list = g->grad_list; io.grad_count = g->counters + CTR_GRAD; io.grad_thr = g->grad_thr; }
+        hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n, 256), 4096)), dim3(256), 0, st, io, values);
+        LAUNCH_CHECK();
+    }
+    return refine_level(g, level, g->cur_udf, g->cur_grads != nullptr, st);
+}
+
+int surfd_grid_grad_points(surfd_grid *g, float *xyz, int64_t capacity, int64_t *n, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_grad_points");
+    if (rc) return rc;
+    if (!g->cur_udf || !n) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_grad_points: call surfd_grid_begin first");
+    int c = 0;
+    HIP_TRY(hipMemcpyAsync(&c, g->counters + CTR_GRAD, sizeof(int), hipMemcpyDeviceToHost, as_stream(s)));
+    HIP_TRY(hipStreamSynchronize(as_stream(s)));
+    *n = c;
+    if (!xyz || c == 0) return SURFD_OK;
+    if (capacity < c) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_grad_points: capacity %lld < %d points", (long long)capacity, c);
+    PtIO io = base_io(g);
+    io.mode = PT_LIST; io.list = g->grad_list; io.n = c;
+    hipLaunchKernelGGL(emit_points_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(c, 256), 4096)), dim3(256), 0,
+                       as_stream(s), io, xyz);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_grad_commit");
+    if (rc) return rc;
+    if (!g->cur_grads) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_grad_commit: no gradient buffer was given to surfd_grid_begin");
+    if (n <= 0) return SURFD_OK;
+    if (!ngrads) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_grad_commit: ngrads is null");
+    hipLaunchKernelGGL(grad_commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n, 256), 4096)), dim3(256), 0,
+                       as_stream(s), (const int *)g->grad_list, (long)n, ngrads, g->cur_grads);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+}  // extern "C"

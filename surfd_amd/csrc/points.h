@@ -1,0 +1,79 @@
+// Point sources / sinks shared by the decoder kernels and the grid-filler kernels.
+//
+// A "point" is either an explicit xyz triple (udf_func on arbitrary points) or a voxel of
+// the N^3 grid addressed by its flat index idx = i*N*N + j*N + k whose coordinate is
+//     x = float(i) * voxel + origin        (two separately rounded fp32 ops)
+// exactly as GridFiller.__init__ builds its `samples` table (reference
+// meshudf/meshudf.py:53-75: column 0 <- i, column 1 <- j, column 2 <- k).
+#pragma once
+#include "common.h"
+
+namespace surfd {
+
+enum PtMode {
+    PT_XYZ = 0,       // xyz[n,3]
+    PT_EMB = 1,       // pre-encoded emb[n,input_dim] (CbnDecoder.forward contract)
+    PT_LIST = 2,      // voxel indices list[count]
+    PT_CHILDREN = 3,  // 7 new lattice children (stride s) of every parent corner in list[count]
+    PT_DENSE = 4,     // every voxel 0..N^3-1
+    PT_LATTICE = 5,   // every point of the stride-s lattice ((N/s)^3 points)
+    PT_CHILDREN8 = 6  // all 8 children incl. the parent itself (classification pass)
+};
+
+struct PtIO {
+    int mode;
+    const float *xyz;        // PT_XYZ / PT_EMB source
+    const int *list;         // PT_LIST / PT_CHILDREN*
+    const int *count_dev;    // device-side element count of `list` (nullable)
+    long n;                  // host-side point count when count_dev == nullptr
+    int N, s;                // grid resolution, lattice stride
+    float voxel, origin;
+    int emb_dim;
+    // sinks (all nullable)
+    float *out_udf, *out_logit, *out_ngrad;   // dense, indexed by point number
+    float *grid_udf, *grid_grads;             // scattered by voxel index
+    int *grad_list;                           // voxels with udf < grad_thr are appended here
+    int *grad_count;
+    float grad_thr;
+};
+
+__device__ __forceinline__ long pt_count(const PtIO &io) {
+    if (io.count_dev == nullptr) return io.n;
+    const long c = *io.count_dev;
+    return io.mode == PT_CHILDREN ? 7 * c : (io.mode == PT_CHILDREN8 ? 8 * c : c);
+}
+
+// voxel index of point e (grid modes only)
+__device__ __forceinline__ int pt_voxel(const PtIO &io, long e) {
+    switch (io.mode) {
+        case PT_LIST: return io.list[e];
+        case PT_CHILDREN: {
+            const int parent = io.list[e / 7];
+            const int c = (int)(e % 7) + 1;
+            return parent + (((c >> 2) & 1) * io.N * io.N + ((c >> 1) & 1) * io.N + (c & 1)) * io.s;
+        }
+        case PT_CHILDREN8: {
+            const int parent = io.list[e >> 3];
+            const int c = (int)(e & 7);
+            return parent + (((c >> 2) & 1) * io.N * io.N + ((c >> 1) & 1) * io.N + (c & 1)) * io.s;
+        }
+        case PT_LATTICE: {
+            const int n = io.N / io.s;
+            const int K = (int)(e % n), J = (int)((e / n) % n), I = (int)(e / ((long)n * n));
+            return (I * io.N * io.N + J * io.N + K) * io.s;
+        }
+        default: return (int)e;   // PT_DENSE
+    }
+}
+
+__device__ __forceinline__ void voxel_xyz(const PtIO &io, int idx, float &x, float &y, float &z) {
+    const int k = idx % io.N, j = (idx / io.N) % io.N, i = idx / (io.N * io.N);
+    x = __fadd_rn(__fmul_rn((float)i, io.voxel), io.origin);
+    y = __fadd_rn(__fmul_rn((float)j, io.voxel), io.origin);
+    z = __fadd_rn(__fmul_rn((float)k, io.voxel), io.origin);
+}
+
+// Enqueue the fused decoder over a point source (defined in decoder.hip).
+int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles_hint, hipStream_t st);
+
+}  // namespace surfd

@@ -1,0 +1,99 @@
+"""Deterministic synthetic weights / noise for tests and benchmarks.
+
+No pretrained checkpoints exist offline and a freshly initialised
+reference model is degenerate: ``zero_module`` zeroes every ResBlock ``out_layers.3``,
+every attention ``proj_out`` and the head conv (reference models/openaimodel.py:229-231,
+312, 685) and the decoder's ``fc_1`` / ``conv_gamma`` / ``conv_beta`` weights are zero
+(AutoEncoder/models/cbndec.py:62-66, 97).  Parity tests on such weights test nothing, so
+both sides (reference-import golden generator, oracle, HIP path, bench) regenerate the
+SAME non-degenerate tensors from the key name alone: a ``torch.Generator`` seeded with
+``crc32(key) ^ seed`` (recipe: SURVEY.md §8d).  Only inputs/outputs are ever committed.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Optional
+
+import torch
+
+from .spec import DecoderConfig, UNetConfig, decoder_param_spec, unet_param_spec
+
+
+def _gen(key: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def _normal(shape, std, key, seed, mean=0.0):
+    return torch.randn(tuple(shape), generator=_gen(key, seed), dtype=torch.float32) * std + mean
+
+
+def synth_unet_state_dict(cfg: UNetConfig = UNetConfig(), seed: int = 0, root: str = "Unet") -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
+    for key, shape in unet_param_spec(cfg, root):
+        leaf = key.rsplit(".", 1)[-1]
+        is_norm = (".in_layers.0." in key or ".out_layers.0." in key or ".norm." in key
+                   or key.startswith(f"{root}.out.0."))
+        if is_norm:
+            sd[key] = _normal(shape, 0.05, key, seed, mean=1.0 if leaf == "weight" else 0.0)
+        elif "label_emb" in key:
+            sd[key] = _normal(shape, 0.1, key, seed)
+        elif leaf == "bias":
+            sd[key] = _normal(shape, 0.02, key, seed)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            gain = 0.5 if (".out_layers.3." in key or ".proj_out." in key) else 1.0
+            sd[key] = _normal(shape, gain / fan_in ** 0.5, key, seed)
+    return sd
+
+
+def synth_decoder_state_dict(cfg: DecoderConfig = DecoderConfig(), seed: int = 0) -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
+    for key, shape in decoder_param_spec(cfg):
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            sd[key] = torch.zeros((), dtype=torch.long)
+        elif leaf == "running_mean":
+            sd[key] = _normal(shape, 0.1, key, seed)
+        elif leaf == "running_var":
+            sd[key] = torch.rand(tuple(shape), generator=_gen(key, seed), dtype=torch.float32) + 0.5
+        elif ".conv_gamma." in key or ".conv_beta." in key:
+            if leaf == "bias":
+                sd[key] = _normal(shape, 0.05, key, seed, mean=1.0 if ".conv_gamma." in key else 0.0)
+            else:
+                sd[key] = _normal(shape, 0.3 / shape[1] ** 0.5, key, seed)
+        elif leaf == "bias":
+            sd[key] = _normal(shape, 0.02, key, seed)
+        else:
+            gain = 0.5 if ".fc_1." in key else 1.0
+            sd[key] = _normal(shape, gain / shape[1] ** 0.5, key, seed)
+    return sd
+
+
+def synth_noise(num_steps: int, sample_index: int, latent_len: int, seed: int = 1234) -> torch.Tensor:
+    """Noise stream of ONE sample: row 0 is x_T, row 1+k is the z drawn at loop step k.
+
+    Seeded per *global* sample index so the result does not depend on how samples are
+    sharded over ranks.  Shape ``[num_steps+1, 1, latent_len]``.
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed * 1000003 + sample_index)
+    return torch.randn(num_steps + 1, 1, latent_len, generator=g, dtype=torch.float32)
+
+
+def synth_noise_batch(num_steps: int, first: int, count: int, latent_len: int, seed: int = 1234) -> torch.Tensor:
+    """``[num_steps+1, count, 1, latent_len]`` for global samples first..first+count-1."""
+    return torch.stack([synth_noise(num_steps, first + i, latent_len, seed) for i in range(count)], dim=1)
+
+
+def synth_context(first: int, count: int, dim: int = 512, seed: int = 77) -> torch.Tensor:
+    """Stand-in for the CLIP embedding: N(0, 0.3^2), per global sample."""
+    rows = []
+    for i in range(count):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed * 1000003 + first + i)
+        rows.append(torch.randn(dim, generator=g, dtype=torch.float32) * 0.3)
+    return torch.stack(rows, 0)

@@ -1,0 +1,194 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the imported reference
+(tools/make_golden.py).  CPU only; no HIP involved."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder as odec
+from oracle import diffusion as odiff
+from oracle import gridfiller as ogrid
+from oracle import unet as ounet
+from surfd_amd import synth
+from surfd_amd.spec import DecoderConfig, UNetConfig, decoder_param_spec, numel, unet_param_spec
+
+T = torch.from_numpy
+
+
+def test_param_counts():
+    # 368 tensors, 138 323 585 parameters (369 / 138 331 649 with labels)
+    spec = unet_param_spec()
+    assert len(spec) == 368
+    assert sum(numel(s) for _, s in spec) == 138_323_585
+    spec = unet_param_spec(UNetConfig(num_classes=9))
+    assert len(spec) == 369
+    assert sum(numel(s) for _, s in spec) == 138_331_649
+    dspec = decoder_param_spec()
+    assert len(dspec) == 101
+    assert sum(numel(s) for k, s in dspec if "running" not in k and "num_batches" not in k) == 3_031_553
+
+
+def test_g1_timestep_embedding(golden):
+    g = golden("g1_timestep_embedding")
+    out = ounet.timestep_embedding(T(g["t"]), 224)
+    np.testing.assert_allclose(out.numpy(), g["emb"], rtol=0, atol=1e-6)
+
+
+def test_g2_schedule(golden):
+    g = golden("g2_schedule")
+    s = odiff.make_schedule("cosine", 1000)
+    np.testing.assert_array_equal(odiff.cosine_betas(1000), g["base_betas"])
+    assert s.timestep_map == list(g["full_timestep_map"])
+    for n in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+              "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+              "posterior_mean_coef1", "posterior_mean_coef2"]:
+        np.testing.assert_array_equal(getattr(s, n), g[n], err_msg=n)
+    d = odiff.make_schedule("cosine", 1000, "ddim50")
+    assert d.timestep_map == list(g["ddim50_timestep_map"]) == list(range(0, 1000, 20))
+    for n in ["betas", "alphas_cumprod", "posterior_mean_coef1", "posterior_log_variance_clipped"]:
+        np.testing.assert_array_equal(getattr(d, n), g["ddim50_" + n], err_msg=n)
+    assert odiff.space_timesteps(300, [10, 15, 20]) == list(g["sections_10_15_20_of_300"])
+    # known values, SURVEY.md §8 a1
+    assert s.betas[0] == pytest.approx(4.128422482196914e-05, rel=1e-9)
+    assert g["base_betas"][999] == 0.999
+
+
+def test_g3_unet_forward(golden, unet_sd):
+    g = golden("g3_unet_nocond_L32")
+    with torch.no_grad():
+        out = ounet.mdm_forward(unet_sd, "no_cond", T(g["x"]), T(g["t"]), {})
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-4, atol=2e-5)
+    g = golden("g3_unet_ctx_L64")
+    with torch.no_grad():
+        out = ounet.mdm_forward(unet_sd, "img", T(g["x"]), T(g["t"]), {"context": T(g["context"])})
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-4, atol=2e-5)
+
+
+def test_g3_unet_category(golden):
+    g = golden("g3_unet_category_L32")
+    sd = synth.synth_unet_state_dict(UNetConfig(num_classes=9))
+    with torch.no_grad():
+        out = ounet.mdm_forward(sd, "category", T(g["x"]), T(g["t"]), {"action_text": T(g["labels"])})
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,kind", [
+    ("input_blocks.1.0", "res"), ("input_blocks.4.0", "res"), ("output_blocks.0.0", "res"),
+    ("output_blocks.5.0", "res"), ("input_blocks.1.1", "attn"), ("middle_block.1", "attn"),
+    ("input_blocks.3.0", "down"), ("output_blocks.2.1", "up"), ("out", "head")])
+def test_g4_modules(golden, unet_sd, name, kind):
+    g = golden("g4_modules_nocond_L32")
+    key = name.replace(".", "__")
+    x = T(g[key + "__in"])
+    p = "Unet." + name
+    with torch.no_grad():
+        if kind == "res":
+            out = ounet.res_block(unet_sd, p, x, T(g[key + "__emb"]))
+        elif kind == "attn":
+            out = ounet.attention_block(unet_sd, p, x)
+        elif kind == "down":
+            out = ounet._conv(unet_sd, p + ".op", x, stride=2)
+        elif kind == "up":
+            out = ounet._conv(unet_sd, p + ".conv", torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest"))
+        else:
+            out = ounet._conv(unet_sd, "Unet.out.2", torch.nn.functional.silu(ounet._gn(unet_sd, "Unet.out.0", x)))
+    np.testing.assert_allclose(out.numpy(), g[key + "__out"], rtol=1e-4, atol=1e-5)
+
+
+def test_g5_single_steps(golden, unet_sd):
+    g = golden("g5_single_steps")
+    x = T(g["x"])
+    model = lambda xx, tt: ounet.unet_forward(unet_sd, xx, tt)
+    s = odiff.make_schedule()
+    with torch.no_grad():
+        for tt in [999, 500, 1, 0]:
+            r = odiff.p_sample(s, model, x, torch.tensor([tt, tt]), T(g[f"z_{tt}"]))
+            np.testing.assert_allclose(r["sample"].numpy(), g[f"sample_{tt}"], rtol=1e-4, atol=2e-5)
+        d = odiff.make_schedule(respacing="ddim50")
+        for tt, eta in [(49, 0.0), (25, 0.0), (0, 0.0), (25, 0.7)]:
+            tag = f"{tt}_eta{int(eta * 10)}"
+            r = odiff.ddim_sample(d, model, x, torch.tensor([tt, tt]), T(g[f"ddim_z_{tag}"]), eta=eta)
+            np.testing.assert_allclose(r["sample"].numpy(), g[f"ddim_sample_{tag}"], rtol=1e-4, atol=2e-5)
+
+
+def test_g6_ddim50_trajectory(golden, unet_sd):
+    g = golden("g6_ddim50_B1_L32")
+    noise = synth.synth_noise_batch(50, 0, 1, 32, seed=int(g["seed"]))
+    model = lambda xx, tt: ounet.unet_forward(unet_sd, xx, tt)
+    x, rec = odiff.sample_loop(odiff.make_schedule(respacing="ddim50"), model, noise, sampler="ddim",
+                               record=[0, 24, 48, 49])
+    for k in [0, 24, 48, 49]:
+        np.testing.assert_allclose(rec[k].numpy(), g[f"x_after_{k}"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(x.numpy(), g["x_after_49"], rtol=1e-3, atol=2e-4)
+
+
+def test_g7_encode(golden):
+    g = golden("g7_encode")
+    np.testing.assert_array_equal(odec.encode(T(g["pts"])).numpy(), g["enc"])
+
+
+@pytest.mark.parametrize("D", [32, 64])
+def test_g8_decoder(golden, D):
+    g = golden(f"g8_decoder_D{D}")
+    sd = synth.synth_decoder_state_dict(DecoderConfig(latent_dim=D))
+    lat, pts = T(g["lat"]), T(g["pts"])
+    with torch.no_grad():
+        logit = odec.decoder_forward(sd, odec.encode(pts[None]), lat)[0]
+    np.testing.assert_allclose(logit.numpy(), g["logit"], rtol=1e-5, atol=1e-5)
+    f = odec.make_udf_func(sd, lat)
+    np.testing.assert_allclose(odec.sample_udf(f, pts, 2 ** 16).numpy(), g["udf"], rtol=0, atol=1e-7)
+    ng = odec.sample_grads(f, pts, 2 ** 12).numpy()
+    cos = (ng * g["ngrad"]).sum(-1)
+    nz = np.linalg.norm(g["ngrad"], axis=-1) > 0
+    assert cos[nz].min() > 1 - 1e-5
+    # kernel-spec algebra == reference graph
+    tab = odec.cbn_tables(sd, lat)[0]
+    with torch.no_grad():
+        udf2, ng2 = odec.udf_and_grad_analytic(sd, tab, pts)
+    np.testing.assert_allclose(udf2.numpy(), g["udf"], rtol=0, atol=2e-7)
+    cos2 = (ng2.numpy() * g["ngrad"]).sum(-1)
+    assert cos2[nz].min() > 1 - 1e-4
+    assert np.abs(ng2.numpy()[~nz]).max(initial=0.0) == 0.0
+
+
+def _sha(t):
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_g10_gridfiller_analytic(golden, N):
+    g = golden("g10_grid_analytic")
+    udf, grads, stats = ogrid.fill_grid(ogrid.analytic_field, N, max_batch=2 ** 30)
+    assert stats["fwd_per_level"] == list(g[f"N{N}_fwd_per_level"])
+    assert stats["grad"] == int(g[f"N{N}_grad_points"])
+    assert _sha(udf) == str(g[f"N{N}_udf_sha256"])        # bit-exact grid
+    assert float(udf.double().sum()) == float(g[f"N{N}_udf_sum"])
+    assert float(grads.double().abs().sum()) == pytest.approx(float(g[f"N{N}_grad_abs_sum"]), rel=1e-9)
+    if N == 64:
+        np.testing.assert_array_equal(udf.numpy(), g["N64_udf"])
+        np.testing.assert_allclose(grads.numpy(), g["N64_grads_f16"].astype(np.float32), atol=1e-3)
+
+
+def test_g10_gridfiller_counts_256(golden):
+    g = golden("g10_grid_analytic")
+    if "N256_fwd_per_level" not in g:
+        pytest.skip("no 256 fixture")
+    udf, _, stats = ogrid.fill_grid(ogrid.analytic_field, 256, max_batch=2 ** 30, with_grads=False)
+    assert stats["fwd_per_level"] == list(g["N256_fwd_per_level"])
+    assert _sha(udf) == str(g["N256_udf_sha256"])
+
+
+def test_g9_gridfiller_decoder(golden, decoder_sd32):
+    g = golden("g9_grid64_decoder")
+    f = odec.make_udf_func(decoder_sd32, T(g["lat"]))
+    udf, grads, stats = ogrid.fill_grid(f, 64, max_batch=2 ** 12)
+    ref = g["udf"]
+    # identical code path on the same machine is normally bit-exact; allow threshold flips
+    close = np.isclose(udf.numpy(), ref, rtol=0, atol=1e-6)
+    assert close.mean() > 0.9999
+    sub = g["grad_idx"]
+    mine = grads.reshape(-1, 3).numpy()[sub]
+    both = (np.linalg.norm(mine, axis=-1) > 0) & (np.linalg.norm(g["grad_sub"], axis=-1) > 0)
+    assert both.mean() > 0.5
+    assert ((mine * g["grad_sub"]).sum(-1)[both] > 1 - 1e-4).mean() > 0.999

@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs ONLY in the build container, where the reference is
+mounted at /root/reference.  It imports the reference's own Python modules (never copies
+them), feeds them the deterministic synthetic weights of surfd_amd.synth, and writes small
+input/output fixtures to tests/golden/*.npz.  The fixtures are data only.
+
+    python tools/make_golden.py [--only g3,g6] [--ref /root/reference]
+
+Import recipe: stub the packages that are not installed and that the hot
+path never calls (open3d, clip, trimesh, pymeshlab, the Cython marching-cubes module) and
+neutralise the hard-coded ``.cuda()`` calls of meshudf.py so everything runs on CPU.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import time
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "tests", "golden")
+
+from surfd_amd.spec import DecoderConfig, UNetConfig  # noqa: E402
+from surfd_amd import synth  # noqa: E402
+
+
+def import_reference(ref: str):
+    sys.path.insert(0, ref)
+    for name in ["open3d", "clip", "trimesh", "pymeshlab", "meshudf._marching_cubes_lewiner"]:
+        sys.modules[name] = MagicMock()
+    torch.Tensor.cuda = lambda self, *a, **k: self          # meshudf.py:78,99,113,121,215,236
+    mods = types.SimpleNamespace()
+    from utils import model_util                              # noqa
+    from diffusion import gaussian_diffusion, respace         # noqa
+    from models import openaimodel, cfg_sampler               # noqa
+    from utils import ldm_utils                               # noqa
+    from AutoEncoder.models import cbndec, coordsenc          # noqa
+    from meshudf import meshudf                               # noqa
+    mods.model_util, mods.gd, mods.respace = model_util, gaussian_diffusion, respace
+    mods.openaimodel, mods.ldm_utils, mods.cfg_sampler = openaimodel, ldm_utils, cfg_sampler
+    mods.cbndec, mods.coordsenc, mods.meshudf = cbndec, coordsenc, meshudf
+    return mods
+
+
+def ref_args(cond_mode: str):
+    return types.SimpleNamespace(cond_mode=cond_mode, arch="OpenUNet", num_actions=9, dataset="deepfashion3d",
+                                 noise_schedule="cosine", sigma_small=True, clip_value=1.0)
+
+
+def build_model(R, cond_mode: str):
+    model, diffusion = R.model_util.create_model_and_diffusion(ref_args(cond_mode))
+    cfg = UNetConfig(num_classes=9 if "category" in cond_mode else None)
+    sd = synth.synth_unet_state_dict(cfg)
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), "spec.py key order differs from the reference"
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    R.model_util.load_model_wo_clip(model, sd)
+    model.eval()            # MDM.train() returns None (models/mdm.py:112-113)
+    return model, diffusion
+
+
+def build_decoder(R, D: int):
+    dec = R.cbndec.CbnDecoder(63, D, 512, 5)
+    sd = synth.synth_decoder_state_dict(DecoderConfig(latent_dim=D))
+    assert list(dec.state_dict().keys()) == list(sd.keys())
+    dec.load_state_dict(sd, strict=True)
+    return dec.eval()
+
+
+def save(name: str, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.0f} KB)")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------
+def g1_g2(R):
+    t = torch.tensor([0, 1, 500, 999])
+    save("g1_timestep_embedding", t=t, emb=R.ldm_utils.timestep_embedding(t, 224))
+    d = R.model_util.create_gaussian_diffusion(ref_args("no_cond"))
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    arrs = {n: getattr(d, n) for n in names}
+    base = R.gd.get_named_beta_schedule("cosine", 1000, 1.0)
+    dd = R.respace.SpacedDiffusion(use_timesteps=R.respace.space_timesteps(1000, "ddim50"), betas=base,
+                                   model_mean_type=R.gd.ModelMeanType.START_X,
+                                   model_var_type=R.gd.ModelVarType.FIXED_SMALL, loss_type=R.gd.LossType.MSE,
+                                   rescale_timesteps=False, args=ref_args("no_cond"))
+    for n in names:
+        arrs["ddim50_" + n] = getattr(dd, n)
+    arrs["ddim50_timestep_map"] = np.array(dd.timestep_map)
+    arrs["full_timestep_map"] = np.array(d.timestep_map)
+    arrs["base_betas"] = base
+    arrs["sections_10_15_20_of_300"] = np.array(sorted(R.respace.space_timesteps(300, [10, 15, 20])))
+    save("g2_schedule", **arrs)
+
+
+def g3_g4(R):
+    # full forwards + per-module activations captured with forward hooks
+    model, _ = build_model(R, "no_cond")
+    x = rnd((2, 1, 32), 11)
+    t = torch.tensor([999, 10])
+    captured = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            captured[name + ".in"] = inp[0].detach().clone()
+            if len(inp) > 1 and isinstance(inp[1], torch.Tensor):
+                captured[name + ".emb"] = inp[1].detach().clone()
+            captured[name + ".out"] = out.detach().clone()
+        return fn
+
+    U = model.Unet
+    targets = {
+        "input_blocks.1.0": U.input_blocks[1][0], "input_blocks.1.1": U.input_blocks[1][1],
+        "input_blocks.3.0": U.input_blocks[3][0], "input_blocks.4.0": U.input_blocks[4][0],
+        "middle_block.1": U.middle_block[1], "output_blocks.0.0": U.output_blocks[0][0],
+        "output_blocks.2.1": U.output_blocks[2][1], "output_blocks.5.0": U.output_blocks[5][0],
+        "out": U.out,
+    }
+    hs = [m.register_forward_hook(hook(n)) for n, m in targets.items()]
+    # checkpoint() re-enters modules under no_grad only; hooks on the module still fire once
+    with torch.no_grad():
+        y = model(x, t, y={})
+    for h in hs:
+        h.remove()
+    save("g3_unet_nocond_L32", x=x, t=t, out=y)
+    save("g4_modules_nocond_L32", **{k.replace(".", "__"): v for k, v in captured.items()})
+
+    model, _ = build_model(R, "img")
+    x = rnd((2, 1, 64), 12)
+    ctx = rnd((2, 512), 13, 0.3)
+    with torch.no_grad():
+        y = model(x, torch.tensor([777, 3]), y={"context": ctx})
+    save("g3_unet_ctx_L64", x=x, t=torch.tensor([777, 3]), context=ctx, out=y)
+
+    model, _ = build_model(R, "category")
+    x = rnd((2, 1, 32), 14)
+    lab = torch.tensor([3, 7])
+    with torch.no_grad():
+        y = model(x, torch.tensor([500, 0]), y={"action_text": lab})
+    save("g3_unet_category_L32", x=x, t=torch.tensor([500, 0]), labels=lab, out=y)
+
+
+class NoiseFeeder:
+    """Replaces th.randn_like inside the reference's gaussian_diffusion module."""
+    def __init__(self, stream):
+        self.stream, self.k = stream, 0
+
+    def __call__(self, x):
+        z = self.stream[self.k]
+        self.k += 1
+        assert z.shape == x.shape
+        return z.clone()
+
+
+def g5_g6(R):
+    model, diff = build_model(R, "no_cond")
+    th = R.gd.th
+    real = th.randn_like
+    try:
+        # G5: single steps with injected z
+        x = rnd((2, 1, 32), 21)
+        out = {"x": x}
+        for tt in [999, 500, 1, 0]:
+            z = rnd((2, 1, 32), 100 + tt)
+            th.randn_like = NoiseFeeder([z])
+            with torch.no_grad():
+                r = diff.p_sample(model, x, torch.tensor([tt, tt]), clip_denoised=False, model_kwargs={"y": {}})
+            out[f"z_{tt}"], out[f"sample_{tt}"], out[f"x0_{tt}"] = z, r["sample"], r["pred_xstart"]
+        base = R.gd.get_named_beta_schedule("cosine", 1000, 1.0)
+        dd = R.respace.SpacedDiffusion(use_timesteps=R.respace.space_timesteps(1000, "ddim50"), betas=base,
+                                       model_mean_type=R.gd.ModelMeanType.START_X,
+                                       model_var_type=R.gd.ModelVarType.FIXED_SMALL, loss_type=R.gd.LossType.MSE,
+                                       rescale_timesteps=False, args=ref_args("no_cond"))
+        for tt, eta in [(49, 0.0), (25, 0.0), (0, 0.0), (25, 0.7)]:
+            z = rnd((2, 1, 32), 200 + tt)
+            th.randn_like = NoiseFeeder([z])
+            with torch.no_grad():
+                r = dd.ddim_sample(model, x, torch.tensor([tt, tt]), clip_denoised=False, model_kwargs={"y": {}}, eta=eta)
+            tag = f"{tt}_eta{int(eta * 10)}"
+            out[f"ddim_z_{tag}"], out[f"ddim_sample_{tag}"] = z, r["sample"]
+        save("g5_single_steps", **out)
+
+        # G6a: 50-step DDIM trajectory (config C1: B=1, L=32, eta=0)
+        noise = synth.synth_noise_batch(50, 0, 1, 32)
+        th.randn_like = NoiseFeeder(list(noise[1:]))
+        rec = {}
+        with torch.no_grad():
+            for k, o in enumerate(dd.ddim_sample_loop_progressive(model, (1, 1, 32), noise=noise[0].clone(),
+                                                                  clip_denoised=False, model_kwargs={"y": {}}, eta=0.0)):
+                if k in (0, 24, 48, 49):
+                    rec[f"x_after_{k}"] = o["sample"].clone()
+        save("g6_ddim50_B1_L32", seed=1234, **rec)
+
+        # G6b: 1000-step DDPM trajectory (B=2, L=32)
+        noise = synth.synth_noise_batch(1000, 0, 2, 32)
+        th.randn_like = NoiseFeeder(list(noise[1:]))
+        rec = {}
+        t0 = time.time()
+        with torch.no_grad():
+            for k, o in enumerate(diff.p_sample_loop_progressive(model, (2, 1, 32), noise=noise[0].clone(),
+                                                                 clip_denoised=False, model_kwargs={"y": {}})):
+                if k in (0, 1, 499, 998, 999):
+                    rec[f"x_after_{k}"] = o["sample"].clone()
+        print(f"  reference 1000-step DDPM loop B=2: {time.time() - t0:.1f}s")
+        save("g6_ddpm1000_B2_L32", seed=1234, **rec)
+    finally:
+        th.randn_like = real
+
+
+def make_ref_udf(R, dec, lat):
+    enc = R.coordsenc.CoordsEncoder()
+
+    def udf_func(c):
+        e = enc.encode(c.unsqueeze(0))
+        p = dec(e, lat).squeeze(0)
+        p = torch.sigmoid(p)
+        return (1 - p) * 0.1
+    return udf_func
+
+
+def g7_g8(R):
+    enc = R.coordsenc.CoordsEncoder()
+    pts = torch.rand(16, 3, generator=torch.Generator().manual_seed(31)) * 2 - 1
+    save("g7_encode", pts=pts, enc=enc.encode(pts))
+    for D in (32, 64):
+        dec = build_decoder(R, D)
+        lat = rnd((1, D), 40 + D, 0.8)
+        pts = torch.rand(4096, 3, generator=torch.Generator().manual_seed(41 + D)) * 2 - 1
+        f = make_ref_udf(R, dec, lat)
+        with torch.no_grad():
+            logit = dec(enc.encode(pts.unsqueeze(0)), lat).squeeze(0)
+        udf = R.meshudf.sample_udf(f, pts, 2 ** 16)
+        grads = R.meshudf.sample_grads(f, pts, 2 ** 12)
+        save(f"g8_decoder_D{D}", lat=lat, pts=pts, logit=logit, udf=udf, ngrad=grads)
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def g9(R):
+    dec = build_decoder(R, 32)
+    lat = rnd((1, 32), 51, 0.8)
+    f = make_ref_udf(R, dec, lat)
+    calls = []
+
+    def counting(c):
+        calls.append(c.shape[0])
+        return f(c)
+    t0 = time.time()
+    gf = R.meshudf.GridFiller(64)
+    udf, grads = gf.fill_grid(counting, 2 ** 12)
+    print(f"  reference GridFiller(64) with synthetic decoder: {time.time() - t0:.1f}s, {sum(calls)} queries")
+    udf, grads = udf.detach(), grads.detach()
+    sub = torch.arange(0, 64 ** 3, 5)
+    save("g9_grid64_decoder", lat=lat, udf=udf, grad_idx=sub, grad_sub=grads.reshape(-1, 3)[sub],
+         grad_nonzero=int((grads.abs().sum(-1) > 0).sum()), udf_sum=float(udf.double().sum()))
+
+
+def g10(R, sizes):
+    from oracle.gridfiller import analytic_field
+    res = {}
+    for N in sizes:
+        per_call = []
+
+        def counting(c):
+            per_call.append(c.shape[0])
+            return analytic_field(c)
+        t0 = time.time()
+        gf = R.meshudf.GridFiller(N)
+        udf, grads = gf.fill_grid(counting, 2 ** 30)      # one call per level, then one gradient call
+        nl = len(gf.N_levels)
+        res[f"N{N}_fwd_per_level"] = np.array(per_call[:nl])
+        res[f"N{N}_grad_points"] = np.array(sum(per_call[nl:]))
+        res[f"N{N}_udf_sum"] = np.array(float(udf.double().sum()))
+        res[f"N{N}_udf_sha256"] = np.array(sha(udf))
+        res[f"N{N}_grad_abs_sum"] = np.array(float(grads.double().abs().sum()))
+        res[f"N{N}_grad_nonzero"] = np.array(int((grads != 0).any(-1).sum()))
+        if N <= 64:
+            res[f"N{N}_udf"] = udf.numpy()
+            res[f"N{N}_grads_f16"] = grads.numpy().astype(np.float16)
+        print(f"  reference GridFiller({N}) analytic: {time.time() - t0:.1f}s  fwd={per_call[:nl]} grad={sum(per_call[nl:])}")
+        del gf, udf, grads
+    save("g10_grid_analytic", **res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--g10-sizes", default="64,128,256")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    R = import_reference(a.ref)
+    jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
+            "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")])}
+    only = [s for s in a.only.split(",") if s]
+    for name, fn in jobs.items():
+        if only and name not in only:
+            continue
+        print(f"[{name}]")
+        fn()
+
+
+if __name__ == "__main__":
+    main()
