@@ -132,9 +132,11 @@ int surfd_decoder_logits_emb(surfd_decoder *d, int sample, const float *emb, int
 int surfd_decoder_udf(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf,
                       float *logits, surfd_stream s);
 /* sample_grads: ngrad[n,3] = -normalize(d udf/d p) (eps 1e-12; exact zero vector where the
- * fp32 sigmoid derivative vanishes); udf (nullable) as above */
+ * fp32 sigmoid derivative vanishes); udf (nullable) as above; dlogit (nullable) receives the
+ * raw d logit / d p [n,3] (what an autograd backward through CbnDecoder.forward needs).
+ * At least one of ngrad / dlogit must be given. */
 int surfd_decoder_udf_grad(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf,
-                           float *ngrad, surfd_stream s);
+                           float *ngrad, float *dlogit, surfd_stream s);
 
 /* ------------------------------------------------------------------------------------ */
 /* UDF grid: GridFiller / get_udf_and_grads (meshudf/meshudf.py:23-304)                  */

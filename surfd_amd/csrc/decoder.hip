@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                     const float ox = -(gx / nrm), oy = -(gy / nrm), oz = -(gz / nrm);
                     if (io.out_logit) io.out_logit[e] = o;
                     if (io.out_udf) io.out_udf[e] = udf;
+                    if (io.out_dlogit) { io.out_dlogit[e * 3 + 0] = DV[tid * 4 + 0]; io.out_dlogit[e * 3 + 1] = DV[tid * 4 + 1]; io.out_dlogit[e * 3 + 2] = DV[tid * 4 + 2]; }
                     if (io.out_ngrad) { io.out_ngrad[e * 3 + 0] = ox; io.out_ngrad[e * 3 + 1] = oy; io.out_ngrad[e * 3 + 2] = oz; }
                     if (io.grid_grads) {
                         const long vox = __float_as_int(PT[tid * 4 + 3]);
@@ -764,11 +765,12 @@ int surfd_decoder_udf(surfd_decoder *d, int sample, const float *pts, int64_t n,
     return decoder_launch(d, sample, io, false, ceil_div<long>(n, TP), as_stream(s));
 }
 
-int surfd_decoder_udf_grad(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf, float *ngrad, surfd_stream s) {
-    if (!pts || !ngrad || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf_grad: bad argument");
+int surfd_decoder_udf_grad(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf, float *ngrad,
+                           float *dlogit, surfd_stream s) {
+    if (!pts || (!ngrad && !dlogit) || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf_grad: bad argument");
     if (n == 0) return SURFD_OK;
     PtIO io = make_io(PT_XYZ, pts, n);
-    io.out_udf = udf; io.out_ngrad = ngrad;
+    io.out_udf = udf; io.out_ngrad = ngrad; io.out_dlogit = dlogit;
     return decoder_launch(d, sample, io, true, ceil_div<long>(n, TP), as_stream(s));
 }
 

@@ -31,6 +31,7 @@ struct PtIO {
     int emb_dim;
     // sinks (all nullable)
     float *out_udf, *out_logit, *out_ngrad;   // dense, indexed by point number
+    float *out_dlogit;                        // dense [n,3]: raw d logit / d xyz (autograd hook)
     float *grid_udf, *grid_grads;             // scattered by voxel index
     int *grad_list;                           // voxels with udf < grad_thr are appended here
     int *grad_count;

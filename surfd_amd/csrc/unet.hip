@@ -1,0 +1,976 @@
+// The latent denoiser (1-D UNet, reference models/openaimodel.py:413-749 as configured by
+// models/mdm.py:34-57) on gfx950: execution plan + three kernels.
+//
+//   conv_kernel  — every Conv1d / Linear of the network as ONE implicit-GEMM kernel family on
+//                  fp32 MFMA (v_mfma_f32_32x32x2_f32), with the producer-side elementwise work
+//                  fused in: GroupNorm32 statistics + affine + SiLU on the operand while it is
+//                  staged through LDS (openaimodel.py:255-275, utils/ldm_utils.py:213-230),
+//                  im2col for k=3 / stride-2 (Downsample :134-160) / nearest-x2 upsample
+//                  (Upsample :91-119), channel concat of the skip connection as a second
+//                  K-segment (1x1 skip_connection conv, :240-241), and in the epilogue bias,
+//                  the per-(t,sample) ResBlock embedding add (:264-271) and the residual add.
+//   attn_kernel  — QKVAttentionLegacy (:356-372) for one (sample, head): sequence length <= 64,
+//                  head dims 28/56/112, softmax in fp32; 0.4 % of the FLOPs, plain VALU.
+//   temb_kernel  — timestep_embedding (utils/ldm_utils.py:165-185).
+//
+// Everything that depends only on (timestep, conditioning) — time_embed MLP, label/context
+// embedding, the 22 ResBlock emb_layers (openaimodel.py:724-735, 218-224) — is evaluated for
+// ALL loop iterations up front by the same conv_kernel (rows = steps x samples), so one
+// denoiser evaluation inside the loop is 98 conv launches + 16 attention launches.
+//
+// Weights are streamed once per evaluation from HBM/MALL in the fragment-major packing of
+// common.h (k order inside a segment: tap-major, channel-minor, channels padded to 8).
+#include "common.h"
+#include "unet_api.h"
+#include <string.h>
+#include <algorithm>
+
+namespace surfd {
+
+// ---------------------------------------------------------------------------------------------
+// conv kernel
+// ---------------------------------------------------------------------------------------------
+struct SegArgs {
+    const float *x;        // source view (channel offset applied)
+    long bstride;          // floats between consecutive batch entries
+    int C, Cp;             // channels, padded to 8
+    int Lin;               // source length
+    int taps, stride, ups; // 1|3, 1|2, 0|1
+    int gn, act;           // GroupNorm32 on this operand / SiLU on this operand
+    int bmod;              // >0: source batch index = b % bmod
+    const float *gamma, *beta;
+    int kg_off;            // first k-group of this segment in the packed K axis
+    int cc;                // channels staged per chunk (multiple of 8; whole GN groups)
+};
+
+struct ConvArgs {
+    SegArgs seg[2];
+    int nseg;
+    const float *wp;       // packed [ntiles][KGtot][64][4]
+    int KGtot;
+    const float *bias;     // [Cout] or null
+    const float *emb;      // emb[b * emb_bstride + co] or null
+    long emb_bstride;
+    const float *res;      // res[b * res_bstride + co * Lout + l] or null
+    long res_bstride;
+    float *out;
+    long out_bstride;
+    int Cout, Lout, B;
+    int bchunk;            // batch entries per workgroup
+    int Lsl;               // staged positions per batch entry
+    int cs_max;            // LDS row stride of the largest chunk (floats)
+};
+
+constexpr int CONV_CT_MAX = 4;   // column tiles (32 output positions each) per wave
+
+__device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int b0 = blockIdx.y * A.bchunk;
+    const int nb = min(A.bchunk, A.B - b0);
+    const int M = nb * A.Lout;
+    const int nct = (M + 31) >> 5;
+    // wave roles: column tiles round-robin; spare waves split K instead
+    int KP = 1;
+    if (nct == 1) KP = 4; else if (nct == 2) KP = 2;
+    const int kpart = (KP == 1) ? 0 : wave / nct;
+    const int ct0 = (KP == 1) ? wave : wave % nct;
+    const int ct_step = (KP == 1) ? 4 : nct;
+    const bool active = ct0 < nct;
+
+    f32x16 acc[CONV_CT_MAX];
+#pragma unroll
+    for (int i = 0; i < CONV_CT_MAX; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // per-lane column (output position) bookkeeping
+    int colb[CONV_CT_MAX], coll[CONV_CT_MAX];
+#pragma unroll
+    for (int i = 0; i < CONV_CT_MAX; ++i) {
+        int m = (ct0 + i * ct_step) * 32 + (lane & 31);
+        if (m >= M) m = 0;
+        colb[i] = m / A.Lout;
+        coll[i] = m % A.Lout;
+    }
+    const f32x4 *wbase = reinterpret_cast<const f32x4 *>(A.wp) + (size_t)tile * A.KGtot * 64 + lane;
+    float *red = lds + (size_t)A.bchunk * A.Lsl * A.cs_max;   // [3][64*16] cross-wave K reduction scratch
+
+    for (int si = 0; si < A.nseg; ++si) {
+        const SegArgs S = A.seg[si];
+        const int pad = S.taps == 3 ? 1 : 0;
+        const int gs = S.gn ? S.C / 32 : 1;
+        const int kgs_per_tap = S.Cp >> 3;
+        for (int c0 = 0; c0 < S.Cp; c0 += S.cc) {
+            const int cc = min(S.cc, S.Cp - c0);
+            const int cs = cc + 4;
+            __syncthreads();   // previous chunk's MFMA reads are done
+            // ---- stage raw operand chunk: slab[b][p][c] -------------------------------------
+            const int total = nb * A.Lsl * cc;
+            for (int e = tid; e < total; e += 256) {
+                // source-friendly order: l fastest (contiguous in global), then c, then b
+                const int p = e % A.Lsl;
+                const int c = (e / A.Lsl) % cc;
+                const int b = e / (A.Lsl * cc);
+                const int sidx = p - pad;
+                float v = 0.f;
+                const int cg = c0 + c;
+                if (cg < S.C) {
+                    int bs = b0 + b;
+                    if (S.bmod) bs %= S.bmod;
+                    if (S.ups) {
+                        if (sidx >= 0 && sidx < 2 * S.Lin) v = S.x[bs * S.bstride + (long)cg * S.Lin + (sidx >> 1)];
+                    } else if (sidx >= 0 && sidx < S.Lin) {
+                        v = S.x[bs * S.bstride + (long)cg * S.Lin + sidx];
+                    }
+                    if (!S.gn && S.act) v = silu(v);
+                }
+                lds[(b * A.Lsl + p) * cs + c] = v;
+            }
+            __syncthreads();
+            // ---- GroupNorm32 + affine (+ SiLU) in place ---------------------------------------
+            if (S.gn) {
+                const int ng = cc / gs;              // whole groups in this chunk
+                const int cnt = gs * S.Lin;
+                for (int q = wave; q < nb * ng; q += 4) {
+                    const int b = q / ng, g = q % ng;
+                    float *base = lds + (b * A.Lsl + pad) * cs + g * gs;
+                    float s = 0.f;
+                    for (int e = lane; e < cnt; e += 64) s += base[(e % S.Lin) * cs + e / S.Lin];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                    const float mean = s / (float)cnt;
+                    float v2 = 0.f;
+                    for (int e = lane; e < cnt; e += 64) {
+                        const float d = base[(e % S.Lin) * cs + e / S.Lin] - mean;
+                        v2 += d * d;
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v2 += __shfl_xor(v2, off);
+                    const float rstd = 1.f / sqrtf(v2 / (float)cnt + 1e-5f);
+                    for (int e = lane; e < cnt; e += 64) {
+                        const int ci = e / S.Lin;
+                        const int cg = c0 + g * gs + ci;
+                        float *ptr = base + (e % S.Lin) * cs + ci;
+                        float v = (*ptr - mean) * rstd * S.gamma[cg] + S.beta[cg];
+                        if (S.act) v = silu(v);
+                        *ptr = v;
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- MFMA over (tap, 8-channel group) -----------------------------------------------
+            if (active) {
+                const int nkg = cc >> 3;
+                const int iters = S.taps * nkg;
+                for (int it = kpart; it < iters; it += KP) {
+                    const int tap = it / nkg, kgi = it % nkg;
+                    const f32x4 a = wbase[(size_t)(S.kg_off + tap * kgs_per_tap + (c0 >> 3) + kgi) * 64];
+#pragma unroll
+                    for (int i = 0; i < CONV_CT_MAX; ++i) {
+                        if (ct0 + i * ct_step < nct) {
+                            const float *src = lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5));
+                            const f32x4 b = *reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- cross-wave K reduction (only when spare waves split K) --------------------------------
+    if (KP > 1) {
+        __syncthreads();
+        if (active && kpart > 0) {
+            float *dst = red + ((size_t)(kpart - 1) * nct + ct0) * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[0][r];
+        }
+        __syncthreads();
+        if (active && kpart == 0) {
+            for (int kp = 1; kp < KP; ++kp) {
+                const float *srcp = red + ((size_t)(kp - 1) * nct + ct0) * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += srcp[r * 64 + lane];
+            }
+        }
+    }
+    // ---- epilogue: bias + embedding + residual, coalesced along l ------------------------------------
+    if (active && kpart == 0) {
+#pragma unroll
+        for (int i = 0; i < CONV_CT_MAX; ++i) {
+            const int ct = ct0 + i * ct_step;
+            if (ct >= nct) continue;
+            const int m = ct * 32 + (lane & 31);
+            if (m >= M) continue;
+            const int b = b0 + m / A.Lout, l = m % A.Lout;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = tile * 32 + frag_row(r, lane);
+                if (co >= A.Cout) continue;
+                float v = acc[i][r];
+                if (A.bias) v += A.bias[co];
+                if (A.emb) v += A.emb[b * A.emb_bstride + co];
+                if (A.res) v += A.res[b * A.res_bstride + (long)co * A.Lout + l];
+                A.out[b * A.out_bstride + (long)co * A.Lout + l] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention core: one workgroup per (sample, head)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_kernel(const float *qkv, long qkv_bstride, float *out, long out_bstride,
+                                                   int heads, int d, int T, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int tid = threadIdx.x;
+    float *q = lds, *k = q + d * T, *v = k + d * T, *w = v + d * T;   // q,k,v: [d][T]; w: [T][T+1]
+    const float *src = qkv + b * qkv_bstride + (long)h * 3 * d * T;    // head-major [q | k | v] runs
+    for (int e = tid; e < 3 * d * T; e += 256) {
+        float x = src[e];
+        if (e < 2 * d * T) x *= scale;        // (q*scale), (k*scale) as the reference forms them
+        lds[e] = x;
+    }
+    __syncthreads();
+    for (int e = tid; e < T * T; e += 256) {
+        const int t = e / T, s = e % T;
+        float a = 0.f;
+        for (int c = 0; c < d; ++c) a += q[c * T + t] * k[c * T + s];
+        w[t * (T + 1) + s] = a;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+        float mx = -INFINITY;
+        for (int s = 0; s < T; ++s) mx = fmaxf(mx, w[t * (T + 1) + s]);
+        float sum = 0.f;
+        for (int s = 0; s < T; ++s) { const float ex = expf(w[t * (T + 1) + s] - mx); w[t * (T + 1) + s] = ex; sum += ex; }
+        for (int s = 0; s < T; ++s) w[t * (T + 1) + s] /= sum;
+    }
+    __syncthreads();
+    float *dst = out + b * out_bstride + (long)h * d * T;
+    for (int e = tid; e < d * T; e += 256) {
+        const int c = e / T, t = e % T;
+        float a = 0.f;
+        for (int s = 0; s < T; ++s) a += w[t * (T + 1) + s] * v[c * T + s];
+        dst[e] = a;
+    }
+}
+
+// timestep_embedding: out[r][0:half] = cos(t*f_k), out[r][half:] = sin(t*f_k), f_k = exp(-ln(1e4) k / half)
+__global__ void temb_kernel(const int64_t *t, int rows, int dim, float *out) {
+    const int half = dim / 2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * half; e += gridDim.x * blockDim.x) {
+        const int r = e / half, kk = e % half;
+        const float freq = expf(__fdiv_rn(__fmul_rn(-9.210340371976184f, (float)kk), (float)half));
+        const float a = __fmul_rn((float)t[r], freq);
+        out[(long)r * dim + kk] = cosf(a);
+        out[(long)r * dim + half + kk] = sinf(a);
+    }
+}
+
+__global__ void add_label_kernel(float *emb, int rows, int dim, const float *table, const int64_t *cls, int B) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < (long)rows * dim; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / dim), c = (int)(e % dim);
+        emb[e] += table[cls[r % B] * dim + c];
+    }
+}
+
+__global__ void vec_add_kernel(float *dst, const float *a, const float *b, int n) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) dst[e] = a[e] + (b ? b[e] : 0.f);
+}
+
+}  // namespace surfd
+
+// =============================================================================================
+// host: plan
+// =============================================================================================
+using namespace surfd;
+
+namespace {
+
+struct ParamInfo {
+    std::string key;
+    std::vector<int64_t> shape;
+    bool is_set = false;
+};
+
+struct View { int buf = -1; int choff = 0; };   // buf: index into buffers, -2 = external input, -3 = external output
+
+struct BufInfo { int C; int ds; };               // [B][C][L/ds]
+
+struct SegPlan {
+    View src;
+    int C = 0, taps = 1, stride = 1, ups = 0, gn = 0, act = 0;
+    std::string wkey;      // weight tensor packed into this segment
+    std::string gnkey;     // "<prefix>" of GroupNorm weight/bias
+    int ds = 1;            // source ds (ds == 0: length-1 "linear" operand)
+};
+
+struct ConvPlan {
+    SegPlan seg[2];
+    int nseg = 1;
+    int Cout = 0;
+    int ds_out = 1;
+    std::vector<std::string> bias_keys;   // summed
+    int emb_off = -1;
+    View res, dst;
+    // resolved at finalize
+    size_t w_off = 0; int KGtot = 0; int kg_off[2] = {0, 0}; size_t bias_off = 0; int gn_off[2] = {-1, -1};
+};
+
+struct AttnPlan { View qkv, out; int C = 0, ds = 1; };
+
+struct Op { int kind; ConvPlan conv; AttnPlan attn; };   // 0 conv, 1 attn
+
+}  // namespace
+
+struct surfd_unet {
+    surfd_unet_cfg cfg;
+    int ted = 0;                                  // time-embed dim
+    std::vector<ParamInfo> params;
+    std::map<std::string, int> pindex;
+    std::vector<BufInfo> bufs;
+    std::vector<Op> ops;                          // denoiser body, in execution order
+    ConvPlan lin1, lin2, lin3;                    // embedding path
+    int emb_total = 0;                            // sum of ResBlock Cout (14112)
+    std::vector<std::pair<std::string, int>> emb_layers;   // (prefix, Cout) in table order
+    // device state
+    bool allocated = false, finalized = false;
+    int device = -1;
+    float *wpack = nullptr; size_t wpack_floats = 0;
+    float *vecs = nullptr; size_t vec_floats = 0;
+    std::map<std::string, size_t> vec_off;        // raw vectors (GN gamma/beta, biases) by key
+    float *label_table = nullptr;
+    // workspace (grow-only)
+    std::vector<float *> buf_ptr; int ws_B = 0, ws_L = 0;
+    float *temb = nullptr, *h1 = nullptr, *emb = nullptr, *emb_table = nullptr; int emb_rows_cap = 0; int emb_rows = 0, emb_B = 0;
+    int64_t *t_dev = nullptr; int t_cap = 0;
+};
+
+namespace {
+
+void add_param(surfd_unet *u, const std::string &k, std::vector<int64_t> shape) {
+    u->pindex[k] = (int)u->params.size();
+    u->params.push_back({k, std::move(shape)});
+}
+
+int new_buf(surfd_unet *u, int C, int ds) { u->bufs.push_back({C, ds}); return (int)u->bufs.size() - 1; }
+
+void add_res_params(surfd_unet *u, const std::string &p, int cin, int cout) {
+    const int64_t ted = u->ted;
+    add_param(u, p + ".in_layers.0.weight", {cin}); add_param(u, p + ".in_layers.0.bias", {cin});
+    add_param(u, p + ".in_layers.2.weight", {cout, cin, 3}); add_param(u, p + ".in_layers.2.bias", {cout});
+    add_param(u, p + ".emb_layers.1.weight", {cout, ted}); add_param(u, p + ".emb_layers.1.bias", {cout});
+    add_param(u, p + ".out_layers.0.weight", {cout}); add_param(u, p + ".out_layers.0.bias", {cout});
+    add_param(u, p + ".out_layers.3.weight", {cout, cout, 3}); add_param(u, p + ".out_layers.3.bias", {cout});
+    if (cin != cout) { add_param(u, p + ".skip_connection.weight", {cout, cin, 1}); add_param(u, p + ".skip_connection.bias", {cout}); }
+}
+
+void add_attn_params(surfd_unet *u, const std::string &p, int c) {
+    add_param(u, p + ".norm.weight", {c}); add_param(u, p + ".norm.bias", {c});
+    add_param(u, p + ".qkv.weight", {3 * c, c, 1}); add_param(u, p + ".qkv.bias", {3 * c});
+    add_param(u, p + ".proj_out.weight", {c, c, 1}); add_param(u, p + ".proj_out.bias", {c});
+}
+
+// ResBlock: dst <- skip(src) + conv2(silu(gn(conv1(silu(gn(src))) + emb)))
+void emit_res(surfd_unet *u, const std::string &p, View src, int cin, int cout, int ds, int scratch1, View dst) {
+    Op a; a.kind = 0;
+    ConvPlan &c1 = a.conv;
+    c1.nseg = 1; c1.Cout = cout; c1.ds_out = ds;
+    c1.seg[0].src = src; c1.seg[0].C = cin; c1.seg[0].taps = 3; c1.seg[0].gn = 1; c1.seg[0].act = 1; c1.seg[0].ds = ds;
+    c1.seg[0].wkey = p + ".in_layers.2.weight"; c1.seg[0].gnkey = p + ".in_layers.0";
+    c1.bias_keys = {p + ".in_layers.2.bias"};
+    c1.emb_off = u->emb_total;
+    u->emb_layers.push_back({p + ".emb_layers.1", cout});
+    u->emb_total += cout;
+    c1.dst = View{scratch1, 0};
+    u->ops.push_back(a);
+    Op b; b.kind = 0;
+    ConvPlan &c2 = b.conv;
+    c2.Cout = cout; c2.ds_out = ds;
+    c2.seg[0].src = View{scratch1, 0}; c2.seg[0].C = cout; c2.seg[0].taps = 3; c2.seg[0].gn = 1; c2.seg[0].act = 1; c2.seg[0].ds = ds;
+    c2.seg[0].wkey = p + ".out_layers.3.weight"; c2.seg[0].gnkey = p + ".out_layers.0";
+    c2.bias_keys = {p + ".out_layers.3.bias"};
+    if (cin != cout) {
+        c2.nseg = 2;
+        c2.seg[1].src = src; c2.seg[1].C = cin; c2.seg[1].taps = 1; c2.seg[1].ds = ds;
+        c2.seg[1].wkey = p + ".skip_connection.weight";
+        c2.bias_keys.push_back(p + ".skip_connection.bias");
+    } else {
+        c2.nseg = 1;
+        c2.res = src;
+    }
+    c2.dst = dst;
+    u->ops.push_back(b);
+}
+
+// AttentionBlock: dst <- src + proj(attn(qkv(gn(src))))
+void emit_attn(surfd_unet *u, const std::string &p, View src, int c, int ds, int qkv_buf, int att_buf, View dst) {
+    Op a; a.kind = 0;
+    ConvPlan &q = a.conv;
+    q.Cout = 3 * c; q.ds_out = ds;
+    q.seg[0].src = src; q.seg[0].C = c; q.seg[0].taps = 1; q.seg[0].gn = 1; q.seg[0].act = 0; q.seg[0].ds = ds;
+    q.seg[0].wkey = p + ".qkv.weight"; q.seg[0].gnkey = p + ".norm";
+    q.bias_keys = {p + ".qkv.bias"};
+    q.dst = View{qkv_buf, 0};
+    u->ops.push_back(a);
+    Op m; m.kind = 1;
+    m.attn.qkv = View{qkv_buf, 0}; m.attn.out = View{att_buf, 0}; m.attn.C = c; m.attn.ds = ds;
+    u->ops.push_back(m);
+    Op b; b.kind = 0;
+    ConvPlan &pr = b.conv;
+    pr.Cout = c; pr.ds_out = ds;
+    pr.seg[0].src = View{att_buf, 0}; pr.seg[0].C = c; pr.seg[0].taps = 1; pr.seg[0].ds = ds;
+    pr.seg[0].wkey = p + ".proj_out.weight";
+    pr.bias_keys = {p + ".proj_out.bias"};
+    pr.res = src; pr.dst = dst;
+    u->ops.push_back(b);
+}
+
+void emit_plain_conv(surfd_unet *u, const std::string &wprefix, View src, int cin, int cout, int ds_src, int ds_out,
+                     int stride, int ups, View dst) {
+    Op a; a.kind = 0;
+    ConvPlan &c = a.conv;
+    c.Cout = cout; c.ds_out = ds_out;
+    c.seg[0].src = src; c.seg[0].C = cin; c.seg[0].taps = 3; c.seg[0].stride = stride; c.seg[0].ups = ups; c.seg[0].ds = ds_src;
+    c.seg[0].wkey = wprefix + ".weight";
+    c.bias_keys = {wprefix + ".bias"};
+    c.dst = dst;
+    u->ops.push_back(a);
+}
+
+bool in_attn(const surfd_unet_cfg &c, int ds) {
+    for (int i = 0; i < c.n_attn; ++i) if (c.attention_resolutions[i] == ds) return true;
+    return false;
+}
+
+// Mirrors UNetModel.__init__ (openaimodel.py:516-686): parameters in registration order and
+// the op list.  Skip tensors are produced directly inside the concat buffer of the output
+// block that consumes them (zero-copy torch.cat, :742-744).
+int build_plan(surfd_unet *u) {
+    const surfd_unet_cfg &c = u->cfg;
+    const int mc = c.model_channels;
+    u->ted = 4 * mc;
+    const int64_t ted = u->ted;
+    add_param(u, "time_embed.0.weight", {ted, mc}); add_param(u, "time_embed.0.bias", {ted});
+    add_param(u, "time_embed.2.weight", {ted, ted}); add_param(u, "time_embed.2.bias", {ted});
+    if (c.num_classes > 0) add_param(u, "label_emb.weight", {c.num_classes, ted});
+    if (c.context_dim > 0) { add_param(u, "sketch_emb.weight", {ted, c.context_dim}); add_param(u, "sketch_emb.bias", {ted}); }
+
+    // ---- structure pass ----
+    struct InBlk { std::string prefix; int kind; int cin, cout, ds_in, ds_out; bool attn; };   // kind 0 conv,1 res,2 down
+    std::vector<InBlk> in;
+    in.push_back({"input_blocks.0", 0, c.in_channels, mc, 1, 1, false});
+    std::vector<int> chans{mc};
+    std::vector<int> chan_ds{1};
+    int ch = mc, ds = 1;
+    for (int level = 0; level < c.n_mult; ++level) {
+        for (int r = 0; r < c.num_res_blocks; ++r) {
+            const int co = c.channel_mult[level] * mc;
+            in.push_back({"input_blocks." + std::to_string(in.size()), 1, ch, co, ds, ds, in_attn(c, ds)});
+            ch = co; chans.push_back(ch); chan_ds.push_back(ds);
+        }
+        if (level != c.n_mult - 1) {
+            in.push_back({"input_blocks." + std::to_string(in.size()), 2, ch, ch, ds, ds * 2, false});
+            ds *= 2; chans.push_back(ch); chan_ds.push_back(ds);
+        }
+    }
+    const int mid_ch = ch, mid_ds = ds;
+    struct OutBlk { std::string prefix; int ch_h, ich, cout, ds; bool attn, up; };
+    std::vector<OutBlk> out;
+    {
+        std::vector<int> st = chans;
+        int ch2 = ch, ds2 = ds;
+        for (int level = c.n_mult - 1; level >= 0; --level) {
+            for (int i = 0; i <= c.num_res_blocks; ++i) {
+                const int ich = st.back(); st.pop_back();
+                const int co = mc * c.channel_mult[level];
+                const bool up = level && i == c.num_res_blocks;
+                out.push_back({"output_blocks." + std::to_string(out.size()), ch2, ich, co, ds2, in_attn(c, ds2), up});
+                ch2 = co;
+                if (up) ds2 /= 2;
+            }
+        }
+    }
+    const int nin = (int)in.size(), nout = (int)out.size();
+    if (nin != nout) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "unet plan: %d input blocks vs %d output blocks", nin, nout);
+    // ---- buffers ----
+    std::vector<int> cat(nout);
+    int SC = mc;              // widest activation any scratch buffer has to hold
+    for (int k = 0; k < nout; ++k) {
+        cat[k] = new_buf(u, out[k].ch_h + out[k].ich, out[k].ds);
+        SC = std::max(SC, out[k].cout);
+    }
+    for (auto &b : in) SC = std::max(SC, b.cout);
+    // scratch buffers: SC channels at full length (ds = 1) — large enough at every level; a
+    // view's batch stride is (buffer channels) x (length at the level it is used at)
+    const int s1 = new_buf(u, SC, 1), s2 = new_buf(u, SC, 1), s5 = new_buf(u, SC, 1);
+    const int sq = new_buf(u, 3 * SC, 1), sa = new_buf(u, SC, 1);
+    const int fin = new_buf(u, mc, 1);
+    auto hs_view = [&](int j) { const int k = nout - 1 - j; return View{cat[k], out[k].ch_h}; };
+
+    // ---- input blocks ----
+    for (int i = 0; i < nin; ++i) {
+        const InBlk &b = in[i];
+        const View src = (i == 0) ? View{-2, 0} : hs_view(i - 1);
+        const View dst = hs_view(i);
+        const std::string p = b.prefix;
+        if (b.kind == 0) {
+            add_param(u, p + ".0.weight", {b.cout, b.cin, 3}); add_param(u, p + ".0.bias", {b.cout});
+            emit_plain_conv(u, p + ".0", src, b.cin, b.cout, 1, 1, 1, 0, dst);
+        } else if (b.kind == 1) {
+            add_res_params(u, p + ".0", b.cin, b.cout);
+            if (b.attn) add_attn_params(u, p + ".1", b.cout);
+            emit_res(u, p + ".0", src, b.cin, b.cout, b.ds_out, s1, b.attn ? View{s2, 0} : dst);
+            if (b.attn) emit_attn(u, p + ".1", View{s2, 0}, b.cout, b.ds_out, sq, sa, dst);
+        } else {
+            add_param(u, p + ".0.op.weight", {b.cout, b.cin, 3}); add_param(u, p + ".0.op.bias", {b.cout});
+            emit_plain_conv(u, p + ".0.op", src, b.cin, b.cout, b.ds_in, b.ds_out, 2, 0, dst);
+        }
+    }
+    // ---- middle ----
+    {
+        add_res_params(u, "middle_block.0", mid_ch, mid_ch);
+        add_attn_params(u, "middle_block.1", mid_ch);
+        add_res_params(u, "middle_block.2", mid_ch, mid_ch);
+        emit_res(u, "middle_block.0", hs_view(nin - 1), mid_ch, mid_ch, mid_ds, s1, View{s2, 0});
+        emit_attn(u, "middle_block.1", View{s2, 0}, mid_ch, mid_ds, sq, sa, View{s5, 0});
+        emit_res(u, "middle_block.2", View{s5, 0}, mid_ch, mid_ch, mid_ds, s1, View{cat[0], 0});
+    }
+    // ---- output blocks ----
+    for (int k = 0; k < nout; ++k) {
+        const OutBlk &b = out[k];
+        const std::string p = b.prefix;
+        const View src{cat[k], 0};
+        const View dst = (k + 1 < nout) ? View{cat[k + 1], 0} : View{fin, 0};
+        const int cin = b.ch_h + b.ich;
+        add_res_params(u, p + ".0", cin, b.cout);
+        int j = 1;
+        if (b.attn) { add_attn_params(u, p + "." + std::to_string(j), b.cout); ++j; }
+        if (b.up) { add_param(u, p + "." + std::to_string(j) + ".conv.weight", {b.cout, b.cout, 3}); add_param(u, p + "." + std::to_string(j) + ".conv.bias", {b.cout}); }
+        View cur = (b.attn || b.up) ? View{s2, 0} : dst;
+        emit_res(u, p + ".0", src, cin, b.cout, b.ds, s1, cur);
+        j = 1;
+        if (b.attn) {
+            const View nxt = b.up ? View{s5, 0} : dst;
+            emit_attn(u, p + "." + std::to_string(j), cur, b.cout, b.ds, sq, sa, nxt);
+            cur = nxt; ++j;
+        }
+        if (b.up) emit_plain_conv(u, p + "." + std::to_string(j) + ".conv", cur, b.cout, b.cout, b.ds, b.ds / 2, 1, 1, dst);
+    }
+    // ---- head ----
+    add_param(u, "out.0.weight", {mc}); add_param(u, "out.0.bias", {mc});
+    add_param(u, "out.2.weight", {c.out_channels, mc, 3}); add_param(u, "out.2.bias", {c.out_channels});
+    {
+        Op a; a.kind = 0;
+        ConvPlan &h = a.conv;
+        h.Cout = c.out_channels; h.ds_out = 1;
+        h.seg[0].src = View{fin, 0}; h.seg[0].C = mc; h.seg[0].taps = 3; h.seg[0].gn = 1; h.seg[0].act = 1; h.seg[0].ds = 1;
+        h.seg[0].wkey = "out.2.weight"; h.seg[0].gnkey = "out.0";
+        h.bias_keys = {"out.2.bias"};
+        h.dst = View{-3, 0};
+        u->ops.push_back(a);
+    }
+    // ---- embedding path (length-1 operands: ds = 0) ----
+    u->lin1.Cout = (int)ted; u->lin1.seg[0].C = mc; u->lin1.seg[0].ds = 0; u->lin1.seg[0].wkey = "time_embed.0.weight";
+    u->lin1.bias_keys = {"time_embed.0.bias"};
+    u->lin2.Cout = (int)ted; u->lin2.seg[0].C = (int)ted; u->lin2.seg[0].act = 1; u->lin2.seg[0].ds = 0; u->lin2.seg[0].wkey = "time_embed.2.weight";
+    u->lin2.bias_keys = {"time_embed.2.bias"};
+    if (c.context_dim > 0) {
+        u->lin2.nseg = 2;
+        u->lin2.seg[1].C = c.context_dim; u->lin2.seg[1].ds = 0; u->lin2.seg[1].wkey = "sketch_emb.weight";
+        u->lin2.bias_keys.push_back("sketch_emb.bias");
+    }
+    u->lin3.Cout = u->emb_total; u->lin3.seg[0].C = (int)ted; u->lin3.seg[0].act = 1; u->lin3.seg[0].ds = 0;
+    return SURFD_OK;
+}
+
+int seg_kgroups(const SegPlan &s) { return s.taps * (ceil_div(s.C, 8)); }
+
+}  // namespace
+
+// =============================================================================================
+// host: device state
+// =============================================================================================
+namespace {
+
+int unet_alloc(surfd_unet *u) {
+    if (u->allocated) return SURFD_OK;
+    HIP_TRY(hipGetDevice(&u->device));
+    // ---- packed-weight arena layout ----
+    size_t off = 0;
+    auto place = [&](ConvPlan &c) {
+        int kg = 0;
+        for (int s = 0; s < c.nseg; ++s) { c.kg_off[s] = kg; kg += seg_kgroups(c.seg[s]); }
+        c.KGtot = kg;
+        c.w_off = off;
+        off += (size_t)ceil_div(c.Cout, 32) * kg * 256;
+    };
+    for (auto &op : u->ops) if (op.kind == 0) place(op.conv);
+    place(u->lin1); place(u->lin2); place(u->lin3);
+    u->wpack_floats = off;
+    HIP_TRY(hipMalloc((void **)&u->wpack, off * sizeof(float)));
+    HIP_TRY(hipMemset(u->wpack, 0, off * sizeof(float)));
+    // ---- vectors: every 1-D parameter raw, then combined biases ----
+    size_t voff = 0;
+    for (auto &p : u->params)
+        if (p.shape.size() == 1) { u->vec_off[p.key] = voff; voff += (size_t)ceil_div<int64_t>(p.shape[0], 4) * 4; }
+    auto place_bias = [&](ConvPlan &c) { c.bias_off = voff; voff += (size_t)ceil_div(c.Cout, 4) * 4; };
+    for (auto &op : u->ops) if (op.kind == 0) place_bias(op.conv);
+    place_bias(u->lin1); place_bias(u->lin2); place_bias(u->lin3);
+    u->vec_floats = voff;
+    HIP_TRY(hipMalloc((void **)&u->vecs, voff * sizeof(float)));
+    HIP_TRY(hipMemset(u->vecs, 0, voff * sizeof(float)));
+    if (u->cfg.num_classes > 0) HIP_TRY(hipMalloc((void **)&u->label_table, (size_t)u->cfg.num_classes * u->ted * sizeof(float)));
+    const int max_lds = 160 * 1024;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    u->allocated = true;
+    return SURFD_OK;
+}
+
+// packs conv/linear weight `src` ([Cout][C][taps] row-major) into segment s of plan c
+int pack_segment(surfd_unet *u, ConvPlan &c, int s, const float *src, int row_off, int rows, hipStream_t st) {
+    // rows [row_off, row_off + rows) of the plan's output channels come from this tensor
+    const SegPlan &sp = c.seg[s];
+    const int Cp = ceil_div(sp.C, 8) * 8;
+    if (row_off % 32) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "pack_segment: row offset %d not a multiple of 32", row_off);
+    PackDesc pd;
+    pd.src = src;
+    pd.dst = u->wpack + c.w_off + (size_t)(row_off / 32) * c.KGtot * 256;
+    pd.N = rows; pd.K = sp.taps * Cp;
+    pd.Npad = ceil_div(rows, 32) * 32; pd.Kpad = sp.taps * Cp;
+    pd.rs = (long)sp.C * sp.taps;
+    pd.inner = Cp; pd.inner_valid = sp.C;
+    pd.os = 1;          // outer index = tap: stride 1 in [C][taps]
+    pd.is = sp.taps;    // inner index = channel: stride taps
+    pd.KGtot = c.KGtot; pd.kg_off = c.kg_off[s];
+    return launch_pack(pd, st);
+}
+
+struct WeightSite { ConvPlan *plan; int seg; int row_off; };
+
+}  // namespace
+
+extern "C" {
+
+int surfd_unet_create(const surfd_unet_cfg *cfg, surfd_unet **out) {
+    if (!cfg || !out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_create: null argument");
+    if (cfg->n_mult < 1 || cfg->n_mult > 8 || cfg->n_attn < 0 || cfg->n_attn > 8 || cfg->num_heads < 1 ||
+        cfg->model_channels % 32 || cfg->model_channels % cfg->num_heads || cfg->num_res_blocks < 1)
+        SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "surfd_unet_create: unsupported configuration");
+    auto *u = new surfd_unet();
+    u->cfg = *cfg;
+    int rc = build_plan(u);
+    if (rc) { delete u; return rc; }
+    *out = u;
+    return SURFD_OK;
+}
+
+void surfd_unet_destroy(surfd_unet *u) {
+    if (!u) return;
+    if (u->wpack) (void)hipFree(u->wpack);
+    if (u->vecs) (void)hipFree(u->vecs);
+    if (u->label_table) (void)hipFree(u->label_table);
+    for (float *p : u->buf_ptr) if (p) (void)hipFree(p);
+    for (float *p : {u->temb, u->h1, u->emb, u->emb_table}) if (p) (void)hipFree(p);
+    if (u->t_dev) (void)hipFree(u->t_dev);
+    delete u;
+}
+
+int surfd_unet_num_params(const surfd_unet *u) { return u ? (int)u->params.size() : 0; }
+
+int surfd_unet_param_info(const surfd_unet *u, int i, const char **key, int64_t shape[4], int *ndim) {
+    if (!u || i < 0 || i >= (int)u->params.size()) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_param_info: bad index %d", i);
+    *key = u->params[i].key.c_str();
+    *ndim = (int)u->params[i].shape.size();
+    for (int j = 0; j < *ndim; ++j) shape[j] = u->params[i].shape[j];
+    return SURFD_OK;
+}
+
+int surfd_unet_set_param(surfd_unet *u, const char *key, const void *dev_ptr, const int64_t *shape, int ndim, surfd_stream s) {
+    if (!u || !key || !dev_ptr) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_param: null argument");
+    std::string k(key);
+    if (k.rfind("Unet.", 0) == 0) k = k.substr(5);
+    auto it = u->pindex.find(k);
+    if (it == u->pindex.end()) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_param: unexpected key '%s'", key);
+    ParamInfo &p = u->params[it->second];
+    if (ndim != (int)p.shape.size()) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_param: '%s' rank %d, expected %zu", key, ndim, p.shape.size());
+    size_t numel = 1;
+    for (int j = 0; j < ndim; ++j) {
+        if (shape[j] != p.shape[j]) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_param: '%s' dim %d is %lld, expected %lld", key, j, (long long)shape[j], (long long)p.shape[j]);
+        numel *= shape[j];
+    }
+    int rc = unet_alloc(u);
+    if (rc) return rc;
+    hipStream_t st = as_stream(s);
+    const float *src = static_cast<const float *>(dev_ptr);
+    if (ndim == 1) {
+        HIP_TRY(hipMemcpyAsync(u->vecs + u->vec_off[k], src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (k == "label_emb.weight") {
+        HIP_TRY(hipMemcpyAsync(u->label_table, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        // find the plan segment(s) fed by this weight tensor
+        bool placed = false;
+        auto try_plan = [&](ConvPlan &c) -> int {
+            for (int sidx = 0; sidx < c.nseg; ++sidx)
+                if (c.seg[sidx].wkey == k) { placed = true; return pack_segment(u, c, sidx, src, 0, c.Cout, st); }
+            return SURFD_OK;
+        };
+        for (auto &op : u->ops) if (op.kind == 0 && !placed) if ((rc = try_plan(op.conv))) return rc;
+        if (!placed) if ((rc = try_plan(u->lin1))) return rc;
+        if (!placed) if ((rc = try_plan(u->lin2))) return rc;
+        if (!placed) {
+            int row = 0;
+            for (auto &el : u->emb_layers) {
+                if (el.first + ".weight" == k) { placed = true; if ((rc = pack_segment(u, u->lin3, 0, src, row, el.second, st))) return rc; break; }
+                row += el.second;
+            }
+        }
+        if (!placed) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_param: no plan site for '%s'", key);
+    }
+    p.is_set = true;
+    u->finalized = false;
+    return SURFD_OK;
+}
+
+int surfd_unet_finalize(surfd_unet *u, surfd_stream s) {
+    if (!u) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_finalize: null handle");
+    for (auto &p : u->params)
+        if (!p.is_set) SURFD_FAIL(SURFD_ERR_STATE, "surfd_unet_finalize: parameter '%s' was never set", p.key.c_str());
+    hipStream_t st = as_stream(s);
+    // combined biases (e.g. out_layers.3.bias + skip_connection.bias; time_embed.2.bias + sketch_emb.bias)
+    auto combine = [&](ConvPlan &c) -> int {
+        const float *a = u->vecs + u->vec_off[c.bias_keys[0]];
+        const float *b = c.bias_keys.size() > 1 ? u->vecs + u->vec_off[c.bias_keys[1]] : nullptr;
+        hipLaunchKernelGGL(vec_add_kernel, dim3(ceil_div(c.Cout, 256)), dim3(256), 0, st, u->vecs + c.bias_off, a, b, c.Cout);
+        LAUNCH_CHECK();
+        return SURFD_OK;
+    };
+    int rc;
+    for (auto &op : u->ops) if (op.kind == 0) if ((rc = combine(op.conv))) return rc;
+    if ((rc = combine(u->lin1))) return rc;
+    if ((rc = combine(u->lin2))) return rc;
+    // lin3 bias = concatenation of the 22 emb_layers biases (row offsets are multiples of 32 -> 4)
+    int row = 0;
+    for (auto &el : u->emb_layers) {
+        HIP_TRY(hipMemcpyAsync(u->vecs + u->lin3.bias_off + row, u->vecs + u->vec_off[el.first + ".bias"],
+                               (size_t)el.second * sizeof(float), hipMemcpyDeviceToDevice, st));
+        row += el.second;
+    }
+    u->finalized = true;
+    return SURFD_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// host: execution
+// =============================================================================================
+namespace {
+
+int ensure_workspace(surfd_unet *u, int B, int L) {
+    if (u->ws_B >= B && u->ws_L >= L && !u->buf_ptr.empty()) return SURFD_OK;
+    const int nB = std::max(B, u->ws_B), nL = std::max(L, u->ws_L);
+    for (float *p : u->buf_ptr) if (p) HIP_TRY(hipFree(p));
+    u->buf_ptr.assign(u->bufs.size(), nullptr);
+    for (size_t i = 0; i < u->bufs.size(); ++i) {
+        const size_t n = (size_t)nB * u->bufs[i].C * ceil_div(nL, u->bufs[i].ds);
+        HIP_TRY(hipMalloc((void **)&u->buf_ptr[i], n * sizeof(float)));
+    }
+    u->ws_B = nB; u->ws_L = nL;
+    return SURFD_OK;
+}
+
+struct Resolved { float *ptr; long bstride; };
+
+// Launch one planned convolution.  `B` batch entries, operand length Lseg(ds) = ds ? L/ds : 1.
+int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext_in[2], const long ext_in_bs[2],
+                const int ext_bmod[2], float *ext_out, long ext_out_bs, const float *emb, long emb_bs, hipStream_t st) {
+    ConvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nseg = c.nseg; A.Cout = c.Cout; A.B = B;
+    A.Lout = c.ds_out ? L / c.ds_out : 1;
+    A.wp = u->wpack + c.w_off; A.KGtot = c.KGtot;
+    A.bias = u->vecs + c.bias_off;
+    auto resolve = [&](const View &v, int ds, int which, bool is_out) -> Resolved {
+        const int len = ds ? L / ds : 1;
+        if (v.buf >= 0) {
+            const BufInfo &bi = u->bufs[v.buf];
+            const long bs = (long)bi.C * len;
+            return {u->buf_ptr[v.buf] + (long)v.choff * len, bs};
+        }
+        if (is_out) return {ext_out, ext_out_bs};
+        return {const_cast<float *>(ext_in[which]), ext_in_bs[which]};
+    };
+    int max_lsl = 1;
+    for (int s = 0; s < c.nseg; ++s) {
+        const SegPlan &sp = c.seg[s];
+        SegArgs &S = A.seg[s];
+        const Resolved r = resolve(sp.src, sp.ds, s, false);
+        S.x = r.ptr; S.bstride = r.bstride;
+        S.C = sp.C; S.Cp = ceil_div(sp.C, 8) * 8;
+        S.Lin = sp.ds ? L / sp.ds : 1;
+        S.taps = sp.taps; S.stride = sp.stride; S.ups = sp.ups; S.gn = sp.gn; S.act = sp.act;
+        S.bmod = (sp.src.buf < 0) ? ext_bmod[s] : 0;
+        if (sp.gn) { S.gamma = u->vecs + u->vec_off[sp.gnkey + ".weight"]; S.beta = u->vecs + u->vec_off[sp.gnkey + ".bias"]; }
+        S.kg_off = c.kg_off[s];
+        const int lsl = sp.taps == 3 ? (sp.stride == 2 ? 2 * A.Lout + 1 : A.Lout + 2) : A.Lout;
+        max_lsl = std::max(max_lsl, lsl);
+    }
+    A.Lsl = max_lsl;
+    // ---- tiling: batch entries per workgroup and channels per staged chunk -----------------
+    const int budget = 24576;                              // floats of LDS for the slab (96 KB)
+    auto min_cc = [&](const SegPlan &sp) {
+        if (!sp.gn) return 8;
+        const int gs = sp.C / 32;
+        int g = 1;
+        while ((g * gs) % 8) ++g;
+        return g * gs;
+    };
+    int need = 8;
+    for (int s = 0; s < c.nseg; ++s) need = std::max(need, min_cc(c.seg[s]));
+    int bchunk = std::min(B, std::max(1, 512 / A.Lout));
+    while (bchunk > 1 && (long)bchunk * A.Lsl * (need + 4) > budget) --bchunk;
+    if ((long)bchunk * A.Lsl * (need + 4) > 36000)
+        SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand does not fit LDS (L=%d, C=%d)", L, c.seg[0].C);
+    A.bchunk = bchunk;
+    int cs_max = 0;
+    for (int s = 0; s < c.nseg; ++s) {
+        const SegPlan &sp = c.seg[s];
+        const int unit = min_cc(sp);
+        const int Cp = ceil_div(sp.C, 8) * 8;
+        int cc_cap = (int)(budget / ((long)bchunk * A.Lsl)) - 4;
+        int cc = std::max(unit, (cc_cap / unit) * unit);
+        cc = std::min(cc, ceil_div(Cp, unit) * unit);
+        A.seg[s].cc = cc;
+        cs_max = std::max(cs_max, cc + 4);
+    }
+    A.cs_max = cs_max;
+    if (c.emb_off >= 0 && emb) { A.emb = emb + c.emb_off; A.emb_bstride = emb_bs; }
+    if (c.res.buf != -1) { const Resolved r = resolve(c.res, c.ds_out, 0, false); A.res = r.ptr; A.res_bstride = r.bstride; }
+    const Resolved o = resolve(c.dst, c.ds_out, 0, true);
+    A.out = o.ptr; A.out_bstride = o.bstride;
+    const size_t lds_bytes = ((size_t)bchunk * A.Lsl * cs_max + 3 * 1024 * 2) * sizeof(float);
+    dim3 grid(ceil_div(c.Cout, 32), ceil_div(B, bchunk));
+    hipLaunchKernelGGL(conv_kernel, grid, dim3(256), lds_bytes, st, A);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+}  // namespace
+
+namespace surfd {
+
+int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, const float *ctx, const int64_t *cls,
+                                int B, hipStream_t st) {
+    if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
+    if ((u->cfg.num_classes > 0) != (cls != nullptr))
+        SURFD_FAIL(SURFD_ERR_ARG, "unet: class labels must be given if and only if the model is class-conditional");
+    if (ctx && u->cfg.context_dim <= 0) SURFD_FAIL(SURFD_ERR_ARG, "unet: model has no context embedding");
+    if (rows > u->emb_rows_cap) {
+        for (float **p : {&u->temb, &u->h1, &u->emb, &u->emb_table}) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
+        HIP_TRY(hipMalloc((void **)&u->temb, (size_t)rows * u->cfg.model_channels * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&u->h1, (size_t)rows * u->ted * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&u->emb, (size_t)rows * u->ted * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&u->emb_table, (size_t)rows * u->emb_total * sizeof(float)));
+        u->emb_rows_cap = rows;
+    }
+    const int mc = u->cfg.model_channels;
+    hipLaunchKernelGGL(temb_kernel, dim3(std::min(ceil_div(rows * mc / 2, 256), 1024)), dim3(256), 0, st, t_dev, rows, mc, u->temb);
+    LAUNCH_CHECK();
+    int rc;
+    {
+        const float *in[2] = {u->temb, nullptr}; const long bs[2] = {mc, 0}; const int bm[2] = {0, 0};
+        if ((rc = launch_conv(u, u->lin1, rows, 1, in, bs, bm, u->h1, u->ted, nullptr, 0, st))) return rc;
+    }
+    {
+        // without a context the second K-segment is skipped (weights stay packed; nseg is forced to 1)
+        ConvPlan l2 = u->lin2;
+        if (!ctx) {
+            l2.nseg = 1;
+            // bias without sketch_emb.bias: plain time_embed.2.bias
+            const float *in[2] = {u->h1, nullptr}; const long bs[2] = {u->ted, 0}; const int bm[2] = {0, 0};
+            // temporarily point the combined-bias slot at the raw bias
+            const size_t keep = l2.bias_off;
+            l2.bias_off = u->vec_off["time_embed.2.bias"];
+            rc = launch_conv(u, l2, rows, 1, in, bs, bm, u->emb, u->ted, nullptr, 0, st);
+            l2.bias_off = keep;
+            if (rc) return rc;
+        } else {
+            const float *in[2] = {u->h1, ctx}; const long bs[2] = {u->ted, u->cfg.context_dim}; const int bm[2] = {0, B};
+            if ((rc = launch_conv(u, l2, rows, 1, in, bs, bm, u->emb, u->ted, nullptr, 0, st))) return rc;
+        }
+    }
+    if (cls) {
+        hipLaunchKernelGGL(add_label_kernel, dim3(std::min(ceil_div(rows * u->ted, 256), 2048)), dim3(256), 0, st, u->emb, rows,
+                           u->ted, (const float *)u->label_table, cls, B);
+        LAUNCH_CHECK();
+    }
+    {
+        const float *in[2] = {u->emb, nullptr}; const long bs[2] = {u->ted, 0}; const int bm[2] = {0, 0};
+        if ((rc = launch_conv(u, u->lin3, rows, 1, in, bs, bm, u->emb_table, u->emb_total, nullptr, 0, st))) return rc;
+    }
+    u->emb_rows = rows; u->emb_B = B;
+    return SURFD_OK;
+}
+
+int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows, const float *ctx, const int64_t *cls,
+                            int B, hipStream_t st) {
+    if (rows > u->t_cap) {
+        if (u->t_dev) HIP_TRY(hipFree(u->t_dev));
+        u->t_dev = nullptr;
+        HIP_TRY(hipMalloc((void **)&u->t_dev, (size_t)rows * sizeof(int64_t)));
+        u->t_cap = rows;
+    }
+    HIP_TRY(hipMemcpyAsync(u->t_dev, t_rows_host, (size_t)rows * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the host vector may go away after we return
+    return unet_prepare_embeddings_dev(u, u->t_dev, rows, ctx, cls, B, st);
+}
+
+int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st) {
+    if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
+    if (row0 < 0 || row0 + B > u->emb_rows) SURFD_FAIL(SURFD_ERR_STATE, "unet: embedding rows [%d,%d) not prepared", row0, row0 + B);
+    int max_ds = 1;
+    for (auto &b : u->bufs) max_ds = std::max(max_ds, b.ds);
+    if (L % max_ds || L < max_ds || L > 64) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "unet: latent length %d must be a multiple of %d and <= 64", L, max_ds);
+    int rc = ensure_workspace(u, B, L);
+    if (rc) return rc;
+    const float *emb = u->emb_table + (size_t)row0 * u->emb_total;
+    for (auto &op : u->ops) {
+        if (op.kind == 0) {
+            const float *in[2] = {x, x}; const long bs[2] = {(long)u->cfg.in_channels * L, (long)u->cfg.in_channels * L};
+            const int bm[2] = {0, 0};
+            if ((rc = launch_conv(u, op.conv, B, L, in, bs, bm, out, (long)u->cfg.out_channels * L, emb, u->emb_total, st))) return rc;
+        } else {
+            const AttnPlan &a = op.attn;
+            const int T = L / a.ds, heads = u->cfg.num_heads, d = a.C / heads;
+            const float *qkv = u->buf_ptr[a.qkv.buf];
+            float *o = u->buf_ptr[a.out.buf];
+            const long qbs = (long)u->bufs[a.qkv.buf].C * T, obs = (long)u->bufs[a.out.buf].C * T;
+            const float scale = 1.f / sqrtf(sqrtf((float)d));
+            const size_t lds_bytes = ((size_t)3 * d * T + (size_t)T * (T + 1)) * sizeof(float);
+            hipLaunchKernelGGL(attn_kernel, dim3(B * heads), dim3(256), lds_bytes, st, qkv, qbs, o, obs, heads, d, T, scale);
+            LAUNCH_CHECK();
+        }
+    }
+    return SURFD_OK;
+}
+
+}  // namespace surfd
+
+extern "C" int surfd_unet_forward(surfd_unet *u, const float *x, const int64_t *t, const float *ctx, const int64_t *cls,
+                                  float *out, int B, int L, surfd_stream s) {
+    if (!u || !x || !t || !out || B < 1 || L < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_forward: bad argument");
+    hipStream_t st = as_stream(s);
+    int rc = surfd::unet_prepare_embeddings_dev(u, t, B, ctx, cls, B, st);
+    if (rc) return rc;
+    return surfd::unet_forward_prepared(u, x, 0, out, B, L, st);
+}

@@ -1,0 +1,187 @@
+"""Drop-ins for the grid part of the reference's meshudf/meshudf.py, on libsurfd_hip.so.
+
+  GridFiller(N).fill_grid(udf_func, max_batch)   <- meshudf.py:23-206
+  sample_udf / sample_grads                       <- meshudf.py:209-251
+  get_udf_and_grads                               <- meshudf.py:254-304 (dense variant)
+  get_mesh_from_udf                               <- meshudf.py:307-348 (grid + gradients; the
+        marching-cubes / trimesh tail :349-437 is SURVEY.md §8 f1/f2 "next": pass ``mc_fn``)
+
+Two execution modes, same algorithm and same device-side index kernels:
+  * native  — ``udf_func`` was made by ``surfd_amd.cbndec.make_udf_func``: one C call fills
+              udf[N,N,N] and grads[N,N,N,3] with no host round trip (surfd_grid_fill);
+  * callback — any ``udf_func(Tensor[n,3]) -> Tensor[n]`` (the reference contract): per level
+              the device emits the query points, the callable is evaluated in chunks of
+              ``max_batch`` and the values are committed back; gradients by autograd exactly as
+              the reference's sample_grads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import _native as N
+
+
+def sample_udf(udf_func: Callable[[Tensor], Tensor], coords: Tensor, max_batch: int, grad: bool = False) -> Tensor:
+    udf = torch.zeros(coords.shape[0], device=coords.device)
+    start = 0
+    while start < coords.shape[0]:
+        end = min(start + max_batch, coords.shape[0])
+        p = coords[start:end]
+        if grad:
+            udf[start:end] = udf_func(p)
+        else:
+            with torch.no_grad():
+                udf[start:end] = udf_func(p)
+        start = end
+    return udf
+
+
+def sample_grads(udf_func: Callable[[Tensor], Tensor], coords: Tensor, max_batch: int) -> Tensor:
+    native = getattr(udf_func, "_surfd_native", None)
+    if native is not None:                      # fused forward + reverse sweep, no autograd graph
+        dec, lat, sample = native
+        s = dec._bind_single(lat) if sample is None else sample
+        return dec.udf_and_ngrad(coords, s)[1]
+    grads = torch.zeros(coords.shape[0], 3, device=coords.device)
+    start = 0
+    while start < coords.shape[0]:
+        end = min(start + max_batch, coords.shape[0])
+        p = coords[start:end].detach().clone()
+        p.requires_grad = True
+        with torch.enable_grad():
+            udf_func(p).sum().backward()
+        grads[start:end] = -F.normalize(p.grad, dim=1)
+        start = end
+    return grads
+
+
+class GridFiller:
+    """Coarse-to-fine grid evaluation, 32^3 -> ... -> N^3 (see module docstring)."""
+
+    def __init__(self, final_resolution: int, voxel_origin: Tuple[int, int, int] = (-1, -1, -1),
+                 cube_side_length: float = 2.0):
+        if tuple(voxel_origin) != (-1, -1, -1) or cube_side_length != 2.0:
+            raise NotImplementedError("every reference call site uses the default [-1,1]^3 cube")
+        self.N_max = final_resolution
+        self.num_samples = final_resolution ** 3
+        self.N_levels = [32 * (2 ** i) for i in range(int(math.log2(self.N_max) - 4))]
+        self.voxel_origin = voxel_origin
+        self.cube_side_length = cube_side_length
+        self.voxel_size = cube_side_length / (self.N_max - 1)
+        self._handle = None
+        self.last_stats: Optional[Dict] = None
+
+    def _native(self):
+        L = N.lib()
+        if self._handle is None:
+            h = C.c_void_p()
+            N.check(L.surfd_grid_create(self.N_max, C.byref(h)))
+            # thresholds as Python computes them in the reference, rounded to fp32 the way
+            # torch rounds a Python scalar meeting a float32 tensor
+            refine = [float(torch.tensor(1.5 * 1.7 * (2.0 / n), dtype=torch.float32)) for n in self.N_levels]
+            grad_thr = float(torch.tensor(2.5 * self.cube_side_length / self.N_max, dtype=torch.float32))
+            voxel = float(torch.tensor(self.voxel_size, dtype=torch.float32))
+            arr = (C.c_float * len(refine))(*refine)
+            N.check(L.surfd_grid_set_thresholds(h, arr, len(refine), grad_thr, voxel, float(self.voxel_origin[0])))
+            self._handle = h
+        return L, self._handle
+
+    def _stats(self) -> Dict:
+        L, h = self._native()
+        st = N.GridStats()
+        N.check(L.surfd_grid_get_stats(h, C.byref(st), N.stream()))
+        return {"levels": list(st.levels[:st.n_levels]), "fwd_per_level": list(st.fwd_points[:st.n_levels]),
+                "grad": int(st.grad_points)}
+
+    def fill_grid(self, udf_func: Callable[[Tensor], Tensor], max_batch: int, with_grads: bool = True,
+                  out: Optional[Tuple[Tensor, Optional[Tensor]]] = None, stats: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+        L, h = self._native()
+        Nn = self.N_max
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if out is None:
+            udf = torch.empty(Nn, Nn, Nn, device=dev, dtype=torch.float32)
+            grads = torch.empty(Nn, Nn, Nn, 3, device=dev, dtype=torch.float32) if with_grads else None
+        else:
+            udf, grads = out
+        st = N.stream()
+        native = getattr(udf_func, "_surfd_native", None)
+        if native is not None:
+            dec, lat, sample = native
+            s = dec._bind_single(lat) if sample is None else sample
+            _, dh = dec._native()
+            N.check(L.surfd_grid_fill(h, dh, s, N.ptr(udf), N.ptr(grads), st))
+        else:
+            N.check(L.surfd_grid_begin(h, N.ptr(udf), N.ptr(grads), st))
+            n = C.c_int64()
+            for level in range(len(self.N_levels)):
+                N.check(L.surfd_grid_level_points(h, level, None, 0, C.byref(n), st))
+                xyz = torch.empty(max(n.value, 1), 3, device=dev, dtype=torch.float32)
+                N.check(L.surfd_grid_level_points(h, level, N.ptr(xyz), n.value, C.byref(n), st))
+                vals = sample_udf(udf_func, xyz[:n.value], max_batch).float().contiguous()
+                N.check(L.surfd_grid_level_commit(h, level, N.ptr(vals), n.value, st))
+            if with_grads:
+                N.check(L.surfd_grid_grad_points(h, None, 0, C.byref(n), st))
+                if n.value:
+                    xyz = torch.empty(n.value, 3, device=dev, dtype=torch.float32)
+                    N.check(L.surfd_grid_grad_points(h, N.ptr(xyz), n.value, C.byref(n), st))
+                    ng = sample_grads(udf_func, xyz, max_batch).float().contiguous()
+                    N.check(L.surfd_grid_grad_commit(h, N.ptr(ng), n.value, st))
+        if stats:
+            self.last_stats = self._stats()
+        return udf, grads
+
+    def fill_grid_dense(self, udf_func, max_dist: float = 0.1, with_grads: bool = True):
+        """get_udf_and_grads semantics on the native decoder (all N^3 points)."""
+        native = getattr(udf_func, "_surfd_native", None)
+        if native is None:
+            raise RuntimeError("fill_grid_dense needs a udf_func from surfd_amd.make_udf_func")
+        L, h = self._native()
+        dec, lat, sample = native
+        s = dec._bind_single(lat) if sample is None else sample
+        _, dh = dec._native()
+        Nn = self.N_max
+        dev = torch.device("cuda", torch.cuda.current_device())
+        udf = torch.empty(Nn, Nn, Nn, device=dev, dtype=torch.float32)
+        grads = torch.empty(Nn, Nn, Nn, 3, device=dev, dtype=torch.float32) if with_grads else None
+        thr = float(torch.tensor(max_dist - 1e-3, dtype=torch.float32))
+        N.check(L.surfd_grid_fill_dense(h, dh, s, thr, N.ptr(udf), N.ptr(grads), N.stream()))
+        self.last_stats = self._stats()
+        return udf, grads
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                N.lib().surfd_grid_destroy(self._handle)
+        except Exception:
+            pass
+
+
+def get_udf_and_grads(udf_func, coords_range: Tuple[float, float], max_dist: float, N: int, max_batch: int):
+    if tuple(coords_range) != (-1, 1):
+        raise NotImplementedError("every reference call site uses coords_range=(-1, 1)")
+    return GridFiller(N).fill_grid_dense(udf_func, max_dist)
+
+
+def get_mesh_from_udf(udf_func: Callable[[Tensor], Tensor], coords_range: Tuple[float, float], max_dist: float,
+                      N: int = 128, smooth_borders: bool = True, differentiable: bool = True,
+                      max_batch: int = 2 ** 12, use_fast_grid_filler: bool = True, mc_fn=None):
+    """Grid + gradient stage of the reference function.  Returns (udf[N,N,N], grads[N,N,N,3])
+    device tensors when ``mc_fn`` is None; otherwise hands the host arrays to
+    ``mc_fn(udf_np, grads_np, spacing)`` (the udf_mc_lewiner contract)."""
+    if differentiable:
+        raise NotImplementedError("differentiable=True is never used by the sample scripts (SURVEY.md §3.4)")
+    if not use_fast_grid_filler:
+        udf, gradients = get_udf_and_grads(udf_func, coords_range, max_dist, N, max_batch)
+    else:
+        udf, gradients = GridFiller(N).fill_grid(udf_func, max_batch)
+    udf[udf < 0] = 0
+    if mc_fn is None:
+        return udf, gradients
+    spacing = (coords_range[1] - coords_range[0]) / (N - 1)
+    return mc_fn(udf.cpu().numpy(), gradients.cpu().numpy(), [spacing] * 3)
