@@ -101,10 +101,15 @@ def fill_grid_dense(udf_func, N: int, max_dist: float = 0.1, max_batch: int = 2 
 
 def analytic_field(p: Tensor) -> Tensor:
     """Decoder-independent test field of SURVEY.md §8c G10: a hemisphere shell joined to a
-    half torus tube, clipped at 0.1."""
-    r = torch.linalg.norm(p, dim=1)
-    rho = torch.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2)
+    half torus tube, clipped at 0.1.  Written with elementwise IEEE ops only (no reductions),
+    so a point's value does not depend on where it sits in the batch — the device path and the
+    reference enumerate the same points in different orders."""
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    rho2 = x * x + y * y
+    r = torch.sqrt(rho2 + z * z)
+    rho = torch.sqrt(rho2)
     d_up = (r - 0.6).abs()
-    d_dn = torch.sqrt((rho - 0.6) ** 2 + p[:, 2] ** 2)
-    d = torch.where(p[:, 2] >= 0, d_up, d_dn)
+    t = rho - 0.6
+    d_dn = torch.sqrt(t * t + z * z)
+    d = torch.where(z >= 0, d_up, d_dn)
     return torch.clamp(d, max=0.1)

@@ -16,7 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsurfd_hip.so")
 SOURCES = ["core.hip", "decoder.hip", "grid.hip", "unet.hip", "sampler.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
+# -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so with the default
+# "fast" contraction the compiler would fuse the separately rounded steps that mirror torch's
+# fp32 op sequence (grid coordinates, posterior updates) into FMAs.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-ffp-contract=off"]
 
 
 def _hipcc() -> str:

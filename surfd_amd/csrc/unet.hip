@@ -24,6 +24,7 @@
 #include "unet_api.h"
 #include <string.h>
 #include <algorithm>
+#include <stdlib.h>
 
 namespace surfd {
 
@@ -827,7 +828,8 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     }
     A.Lsl = max_lsl;
     // ---- tiling: batch entries per workgroup and channels per staged chunk -----------------
-    const int budget = 24576;                              // floats of LDS for the slab (96 KB)
+    static const int budget_env = getenv("SURFD_CONV_BUDGET") ? atoi(getenv("SURFD_CONV_BUDGET")) : 0;   // debug knob
+    const int budget = budget_env > 0 ? budget_env : 24576;   // floats of LDS for the slab (96 KB)
     auto min_cc = [&](const SegPlan &sp) {
         if (!sp.gn) return 8;
         const int gs = sp.C / 32;

@@ -212,7 +212,8 @@ class SpacedDiffusion:
             return inner
         return None
 
-    def _fused_loop(self, mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device):
+    def _fused_loop(self, mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device,
+                    return_trajectory=False):
         B, L = shape[0], shape[-1]
         T = self.num_timesteps
         if noise_stream is None:
@@ -236,12 +237,13 @@ class SpacedDiffusion:
                            tmap.ctypes.data_as(N.c_i64p), fp(tabs["coef1"]), fp(tabs["coef2"]), fp(tabs["lv"]),
                            fp(tabs["sra"]), fp(tabs["srm1"]), fp(tabs["ab"]), fp(tabs["abp"]))
         out = th.empty(B, *shape[1:], device=device, dtype=th.float32)
+        traj = th.empty(T, B, *shape[1:], device=device, dtype=th.float32) if return_trajectory else None
         Lh, h = mdm._native()
         t0 = time.time()
-        N.check(Lh.surfd_sample_loop(h, C.byref(cfg), N.ptr(noise_stream), N.ptr(ctx), N.ptr(cls), N.ptr(out), None,
+        N.check(Lh.surfd_sample_loop(h, C.byref(cfg), N.ptr(noise_stream), N.ptr(ctx), N.ptr(cls), N.ptr(out), N.ptr(traj),
                                      B, L, N.stream()))
         self.time_con.append(time.time() - t0)
-        return out
+        return (out, traj) if return_trajectory else out
 
     def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               skip_timesteps, init_image, randomize_class, eta, const_noise, noise_stream):
@@ -310,15 +312,18 @@ class SpacedDiffusion:
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                       device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
-                      cond_fn_with_grad=False, dump_steps=None, const_noise=False, noise_stream=None, fused=None):
-        """Same signature as the reference (gaussian_diffusion.py:570-633) plus two extensions:
+                      cond_fn_with_grad=False, dump_steps=None, const_noise=False, noise_stream=None, fused=None,
+                      return_trajectory=False):
+        """Same signature as the reference (gaussian_diffusion.py:570-633) plus extensions:
         ``noise_stream`` [T+1,B,1,L] injects every random draw (row 0 = x_T) for reproducible
-        parity runs; ``fused`` forces (True) or forbids (False) the single-C-call loop."""
+        parity runs; ``fused`` forces (True) or forbids (False) the single-C-call loop;
+        ``return_trajectory`` (fused only) also returns x after every iteration [T,B,1,L]."""
         mdm = self._can_fuse(model, denoised_fn, cond_fn, skip_timesteps, init_image, randomize_class, dump_steps,
                              const_noise, progress, fused)
         if mdm is not None:
             dev = device if device is not None else next(model.parameters()).device
-            return self._fused_loop(mdm, tuple(shape), "ddpm", noise, noise_stream, clip_denoised, model_kwargs, 0.0, dev)
+            return self._fused_loop(mdm, tuple(shape), "ddpm", noise, noise_stream, clip_denoised, model_kwargs, 0.0, dev,
+                                    return_trajectory)
         final, dump = None, []
         for i, sample in enumerate(self.p_sample_loop_progressive(
                 model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,

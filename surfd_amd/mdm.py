@@ -39,7 +39,7 @@ class MDM(nn.Module):
         self.cond_mask_prob = kargs.get("cond_mask_prob", 0.0)
         self.clip_version = clip_version
         self.num_classes = self.num_actions if "category" in self.cond_mode else None
-        self.cfg = UNetConfig(context_dim=clip_dim, num_classes=self.num_classes)
+        self.cfg = kargs.get("unet_cfg") or UNetConfig(context_dim=clip_dim, num_classes=self.num_classes)
         g = torch.Generator().manual_seed(0)
         zero_init = (".out_layers.3.", ".proj_out.", "Unet.out.2.")      # zero_module sites (openaimodel.py:229,312,685)
         for key, shape in unet_param_spec(self.cfg):
