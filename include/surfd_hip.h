@@ -43,6 +43,12 @@ int surfd_abi_version(void);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int surfd_device_count(void);
 
+/* Measurement aid (no reference counterpart): when enabled, the library brackets its dominant
+ * kernels with HIP events on the stream they are launched on.  kind 0 = decoder forward kernel,
+ * 1 = decoder forward+reverse kernel, 2 = whole surfd_sample_loop.  read is host-sync and clears. */
+int surfd_profile_enable(int on);
+int surfd_profile_read(int kind, int64_t *launches, double *total_ms);
+
 /* ------------------------------------------------------------------------------------ */
 /* Denoiser: UNetModel (models/openaimodel.py:413-749) as configured by MDM             */
 /* (models/mdm.py:34-57).                                                               */

@@ -41,6 +41,8 @@ _SIGS = {
     "surfd_last_error": (C.c_char_p, []),
     "surfd_abi_version": (C.c_int, []),
     "surfd_device_count": (C.c_int, []),
+    "surfd_profile_enable": (C.c_int, [C.c_int]),
+    "surfd_profile_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),
     "surfd_unet_create": (C.c_int, [C.POINTER(UNetCfg), C.POINTER(_P)]),
     "surfd_unet_destroy": (None, [_P]),
     "surfd_unet_num_params": (C.c_int, [_P]),

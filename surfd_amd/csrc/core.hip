@@ -39,9 +39,51 @@ int launch_pack(const PackDesc &d, hipStream_t s) {
     return SURFD_OK;
 }
 
+static bool g_prof = false;
+struct ProfPair { hipEvent_t a, b; };
+static std::vector<ProfPair> g_prof_pairs[PROF_KINDS];
+static hipEvent_t g_prof_open[PROF_KINDS];
+
+bool prof_enabled() { return g_prof; }
+void prof_begin(int kind, hipStream_t st) {
+    if (!g_prof) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    g_prof_open[kind] = e;
+}
+void prof_end(int kind, hipStream_t st) {
+    if (!g_prof) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    g_prof_pairs[kind].push_back({g_prof_open[kind], e});
+}
+
 }  // namespace surfd
 
 extern "C" {
+int surfd_profile_enable(int on) {
+    surfd::g_prof = on != 0;
+    return SURFD_OK;
+}
+// host-sync: sums and clears the recorded event pairs of `kind`
+int surfd_profile_read(int kind, int64_t *launches, double *total_ms) {
+    using namespace surfd;
+    if (kind < 0 || kind >= PROF_KINDS || !launches || !total_ms) SURFD_FAIL(SURFD_ERR_ARG, "surfd_profile_read: bad argument");
+    double tot = 0.0;
+    for (auto &p : g_prof_pairs[kind]) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        tot += ms;
+        (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+    }
+    *launches = (int64_t)g_prof_pairs[kind].size();
+    *total_ms = tot;
+    g_prof_pairs[kind].clear();
+    return SURFD_OK;
+}
 const char *surfd_last_error(void) { return surfd::g_err; }
 int surfd_abi_version(void) { return 1; }
 int surfd_device_count(void) {

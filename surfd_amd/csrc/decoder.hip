@@ -336,19 +336,25 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
         __syncthreads();
 
         if constexpr (!GRAD) {
-            if (tid < TP) {
+            if (tid < TP) {          // exactly wave 0: all 64 lanes reach the aggregated append
                 const long e = e0 + tid;
-                if (e < npts) {
+                const bool valid = e < npts;
+                float udf = 0.f;
+                int vox = 0;
+                if (valid) {
                     const float o = LOG[tid];
                     const float y = 1.f / (1.f + expf(-o));
-                    const float udf = (1.f - y) * 0.1f;
+                    udf = (1.f - y) * 0.1f;
                     if (io.out_logit) io.out_logit[e] = o;
                     if (io.out_udf) io.out_udf[e] = udf;
                     if (io.grid_udf) {
-                        const int vox = __float_as_int(PT[tid * 4 + 3]);
+                        vox = __float_as_int(PT[tid * 4 + 3]);
                         io.grid_udf[vox] = udf;
-                        if (io.grad_list && udf < io.grad_thr) io.grad_list[atomicAdd(io.grad_count, 1)] = vox;
                     }
+                }
+                if (io.grid_udf && io.grad_list) {
+                    const int slot = wave_append_slot(io.grad_count, valid && udf < io.grad_thr);
+                    if (slot >= 0) io.grad_list[slot] = vox;
                 }
             }
         }
@@ -730,10 +736,12 @@ int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles
     // one workgroup per CU (LDS-limited); a device-side count is handled by the tile loop
     long blocks = d->num_cus;
     if (ntiles_hint >= 0) blocks = std::min<long>(blocks, std::max<long>(ntiles_hint, 1));
+    prof_begin(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
     if (grad)
         hipLaunchKernelGGL(decoder_kernel<true>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     else
         hipLaunchKernelGGL(decoder_kernel<false>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
+    prof_end(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
     LAUNCH_CHECK();
     return SURFD_OK;
 }

@@ -31,11 +31,19 @@ constexpr int CTR_TOTAL = CTR_GRAD + 1;
 __global__ void classify_kernel(PtIO io, const float *udf, float thr, int *close_list, int *close_count,
                                 int *far_list, int *far_count) {
     const long n = pt_count(io);
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int idx = pt_voxel(io, e);
-        const float v = udf[idx];
-        if (fabsf(v) < thr) close_list[atomicAdd(close_count, 1)] = idx;
-        else far_list[atomicAdd(far_count, 1)] = idx;
+    for (long e0 = blockIdx.x * (long)blockDim.x; e0 < n; e0 += (long)gridDim.x * blockDim.x) {
+        const long e = e0 + threadIdx.x;
+        const bool valid = e < n;
+        int idx = 0;
+        bool close = false;
+        if (valid) {
+            idx = pt_voxel(io, e);
+            close = fabsf(udf[idx]) < thr;
+        }
+        const int sc = wave_append_slot(close_count, valid && close);
+        if (sc >= 0) close_list[sc] = idx;
+        const int sf = wave_append_slot(far_count, valid && !close);
+        if (sf >= 0) far_list[sf] = idx;
     }
 }
 
@@ -44,18 +52,27 @@ __global__ void fill_kernel(const int *far_list, const int *far_count, int s, in
                             float grad_thr, int *grad_list, int *grad_count) {
     const long total = (long)(*far_count) << (3 * log2s);
     const int mask = s - 1;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(e >> (3 * log2s));
-        const int w = (int)(e & ((1 << (3 * log2s)) - 1));
-        const int dk = w & mask, dj = (w >> log2s) & mask, di = w >> (2 * log2s);
-        const int p = far_list[b];
-        const float v = udf[p];
-        if (w != 0) {
-            const int q = p + di * N * N + dj * N + dk;
-            udf[q] = v;
-            // only reachable for fields that go negative: the reference's gradient mask is on
-            // the signed value (meshudf.py:200) while pruning is on |value| (:186)
-            if (grad_list && v < grad_thr) grad_list[atomicAdd(grad_count, 1)] = q;
+    for (long e0 = blockIdx.x * (long)blockDim.x; e0 < total; e0 += (long)gridDim.x * blockDim.x) {
+        const long e = e0 + threadIdx.x;
+        bool want_grad = false;
+        int q = 0;
+        if (e < total) {
+            const int b = (int)(e >> (3 * log2s));
+            const int w = (int)(e & ((1 << (3 * log2s)) - 1));
+            const int dk = w & mask, dj = (w >> log2s) & mask, di = w >> (2 * log2s);
+            const int p = far_list[b];
+            const float v = udf[p];
+            if (w != 0) {
+                q = p + di * N * N + dj * N + dk;
+                udf[q] = v;
+                // only reachable for fields that go negative: the reference's gradient mask is on
+                // the signed value (meshudf.py:200) while pruning is on |value| (:186)
+                want_grad = grad_list != nullptr && v < grad_thr;
+            }
+        }
+        if (grad_list) {
+            const int slot = wave_append_slot(grad_count, want_grad);
+            if (slot >= 0) grad_list[slot] = q;
         }
     }
 }
@@ -71,11 +88,20 @@ __global__ void emit_points_kernel(PtIO io, float *xyz) {
 
 __global__ void commit_kernel(PtIO io, const float *vals) {
     const long n = pt_count(io);
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int idx = pt_voxel(io, e);
-        const float v = vals[e];
-        io.grid_udf[idx] = v;
-        if (io.grad_list && v < io.grad_thr) io.grad_list[atomicAdd(io.grad_count, 1)] = idx;
+    for (long e0 = blockIdx.x * (long)blockDim.x; e0 < n; e0 += (long)gridDim.x * blockDim.x) {
+        const long e = e0 + threadIdx.x;
+        bool want = false;
+        int idx = 0;
+        if (e < n) {
+            idx = pt_voxel(io, e);
+            const float v = vals[e];
+            io.grid_udf[idx] = v;
+            want = io.grad_list != nullptr && v < io.grad_thr;
+        }
+        if (io.grad_list) {
+            const int slot = wave_append_slot(io.grad_count, want);
+            if (slot >= 0) io.grad_list[slot] = idx;
+        }
     }
 }
 

@@ -96,6 +96,7 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     std::vector<int64_t> t_rows((size_t)T * B);
     for (int k = 0; k < T; ++k)
         for (int b = 0; b < B; ++b) t_rows[(size_t)k * B + b] = cfg->timestep_map[T - 1 - k];
+    prof_begin(PROF_LOOP, st);
     int rc = unet_prepare_embeddings(u, t_rows.data(), T * B, ctx, cls, B, st);
     if (rc) return rc;
     // ping-pong the state inside the caller's buffers: x lives in x_out, x0 prediction in a
@@ -118,6 +119,7 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
         if (traj) HIP_TRY(hipMemcpyAsync(x_out, dst, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     (void)hipFreeAsync(x0, st);
+    prof_end(PROF_LOOP, st);
     return rc;
 }
 

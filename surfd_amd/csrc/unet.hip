@@ -60,13 +60,28 @@ struct ConvArgs {
     int bchunk;            // batch entries per workgroup
     int Lsl;               // staged positions per batch entry
     int cs_max;            // LDS row stride of the largest chunk (floats)
+    // cross-workgroup split-K (blockIdx.z = K slice): partial accumulators + arrival counters
+    int KS;
+    float *part;           // [KS][gridDim.y][gridDim.x][part_stride]
+    int part_stride;       // floats per partial tile set (column tiles x 1024)
+    int *counters;         // [gridDim.y][gridDim.x], zero between launches
 };
 
 constexpr int CONV_CT_MAX = 4;   // column tiles (32 output positions each) per wave
+constexpr int CONV_VEC_MAX = 32;  // float4 registers a thread may hold while staging (128 floats)
+constexpr int CONV_U = 8;         // weight fragments fetched per software-pipeline stage
 
 __device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
 
+// LOG2_LV >= 0: operand rows have Lin = 4 << LOG2_LV positions (4..64), staged one (batch, channel)
+//               row per thread as LV float4 loads issued back to back;
+// LOG2_LV < 0 : length-1 operands (the Linear layers of the embedding path), staged as float4
+//               along the channel axis.
+template <int LOG2_LV>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
+    constexpr bool LIN1 = LOG2_LV < 0;
+    constexpr int LV = LIN1 ? 1 : (1 << LOG2_LV);
+    constexpr int RPT = CONV_VEC_MAX / LV;        // rows (or vectors, LIN1) per thread
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
@@ -88,7 +103,6 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // per-lane column (output position) bookkeeping
     int colb[CONV_CT_MAX], coll[CONV_CT_MAX];
 #pragma unroll
     for (int i = 0; i < CONV_CT_MAX; ++i) {
@@ -98,88 +112,222 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
         coll[i] = m % A.Lout;
     }
     const f32x4 *wbase = reinterpret_cast<const f32x4 *>(A.wp) + (size_t)tile * A.KGtot * 64 + lane;
-    float *red = lds + (size_t)A.bchunk * A.Lsl * A.cs_max;   // [3][64*16] cross-wave K reduction scratch
+    float *red = lds + (size_t)A.bchunk * A.Lsl * A.cs_max;   // cross-wave K reduction scratch
+    const int kz = blockIdx.z;
+    int chunk_id = 0;
 
     for (int si = 0; si < A.nseg; ++si) {
         const SegArgs S = A.seg[si];
         const int pad = S.taps == 3 ? 1 : 0;
         const int gs = S.gn ? S.C / 32 : 1;
         const int kgs_per_tap = S.Cp >> 3;
+        const int Lcov = S.ups ? 2 * S.Lin : S.Lin;          // slab positions covered by source data
         for (int c0 = 0; c0 < S.Cp; c0 += S.cc) {
+            if ((chunk_id++) % A.KS != kz) continue;          // K slices are dealt round-robin by chunk
             const int cc = min(S.cc, S.Cp - c0);
             const int cs = cc + 4;
             __syncthreads();   // previous chunk's MFMA reads are done
-            // ---- stage raw operand chunk: slab[b][p][c] -------------------------------------
-            const int total = nb * A.Lsl * cc;
-            for (int e = tid; e < total; e += 256) {
-                // source-friendly order: l fastest (contiguous in global), then c, then b
-                const int p = e % A.Lsl;
-                const int c = (e / A.Lsl) % cc;
-                const int b = e / (A.Lsl * cc);
-                const int sidx = p - pad;
-                float v = 0.f;
-                const int cg = c0 + c;
-                if (cg < S.C) {
-                    int bs = b0 + b;
-                    if (S.bmod) bs %= S.bmod;
-                    if (S.ups) {
-                        if (sidx >= 0 && sidx < 2 * S.Lin) v = S.x[bs * S.bstride + (long)cg * S.Lin + (sidx >> 1)];
-                    } else if (sidx >= 0 && sidx < S.Lin) {
-                        v = S.x[bs * S.bstride + (long)cg * S.Lin + sidx];
+            if constexpr (LIN1) {
+                // ---- length-1 operand: float4 along channels -------------------------------------
+                const int vpr = cc >> 2;                      // vectors per batch row
+                const int nvec = nb * vpr;
+                f32x4 v[RPT];
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int e = tid + 256 * i;
+                    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (e < nvec) {
+                        const int b = e / vpr, j = e % vpr;
+                        int bs = b0 + b;
+                        if (S.bmod) bs %= S.bmod;
+                        const int cg = c0 + 4 * j;
+                        if (cg + 3 < S.C) v[i] = *reinterpret_cast<const f32x4 *>(S.x + bs * S.bstride + cg);
+                        else
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (cg + q < S.C) v[i][q] = S.x[bs * S.bstride + cg + q];
                     }
-                    if (!S.gn && S.act) v = silu(v);
                 }
-                lds[(b * A.Lsl + p) * cs + c] = v;
-            }
-            __syncthreads();
-            // ---- GroupNorm32 + affine (+ SiLU) in place ---------------------------------------
-            if (S.gn) {
-                const int ng = cc / gs;              // whole groups in this chunk
-                const int cnt = gs * S.Lin;
-                for (int q = wave; q < nb * ng; q += 4) {
-                    const int b = q / ng, g = q % ng;
-                    float *base = lds + (b * A.Lsl + pad) * cs + g * gs;
-                    float s = 0.f;
-                    for (int e = lane; e < cnt; e += 64) s += base[(e % S.Lin) * cs + e / S.Lin];
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                    const float mean = s / (float)cnt;
-                    float v2 = 0.f;
-                    for (int e = lane; e < cnt; e += 64) {
-                        const float d = base[(e % S.Lin) * cs + e / S.Lin] - mean;
-                        v2 += d * d;
-                    }
+                for (int i = 0; i < RPT; ++i) {
+                    const int e = tid + 256 * i;
+                    if (e < nvec) {
+                        const int b = e / vpr, j = e % vpr;
+                        f32x4 w = v[i];
+                        if (S.act)
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) v2 += __shfl_xor(v2, off);
-                    const float rstd = 1.f / sqrtf(v2 / (float)cnt + 1e-5f);
-                    for (int e = lane; e < cnt; e += 64) {
-                        const int ci = e / S.Lin;
-                        const int cg = c0 + g * gs + ci;
-                        float *ptr = base + (e % S.Lin) * cs + ci;
-                        float v = (*ptr - mean) * rstd * S.gamma[cg] + S.beta[cg];
-                        if (S.act) v = silu(v);
-                        *ptr = v;
+                            for (int q = 0; q < 4; ++q) w[q] = silu(w[q]);
+                        *reinterpret_cast<f32x4 *>(lds + (b * A.Lsl) * cs + 4 * j) = w;
                     }
                 }
                 __syncthreads();
+            } else {
+                // ---- one (batch, channel) row per thread: LV float4 loads in flight per row ------------
+                const int rows = nb * cc;
+                f32x4 v[RPT][LV];
+                int rb[RPT], rc[RPT];
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = tid + 256 * i;
+                    rb[i] = r / cc; rc[i] = r % cc;
+                    const int cg = c0 + rc[i];
+                    const bool ok = r < rows && cg < S.C;
+                    int bs = b0 + rb[i];
+                    if (S.bmod) bs %= S.bmod;
+                    const f32x4 *src = reinterpret_cast<const f32x4 *>(S.x + bs * S.bstride + (long)cg * S.Lin);
+#pragma unroll
+                    for (int j = 0; j < LV; ++j) v[i][j] = ok ? src[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (S.gn) {
+                    // two-pass GroupNorm statistics without leaving the register file; the small
+                    // exchange arrays alias the (not yet written) slab
+                    float *rowstat = lds;                 // [rows]
+                    float *gstat = lds + rows;            // [nb * ng]
+                    const int ng = cc / gs;
+                    const float inv_cnt = 1.f / (float)(gs * S.Lin);
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + 256 * i;
+                        if (r < rows) {
+                            float sacc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < LV; ++j) sacc += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+                            rowstat[r] = sacc;
+                        }
+                    }
+                    __syncthreads();
+                    for (int q = tid; q < nb * ng; q += 256) {
+                        const float *rp = rowstat + (q / ng) * cc + (q % ng) * gs;
+                        float sacc = 0.f;
+                        for (int j = 0; j < gs; ++j) sacc += rp[j];
+                        gstat[q] = sacc * inv_cnt;
+                    }
+                    __syncthreads();
+                    float mean[RPT];
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + 256 * i;
+                        mean[i] = (r < rows) ? gstat[rb[i] * ng + rc[i] / gs] : 0.f;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + 256 * i;
+                        if (r < rows) {
+                            float sacc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < LV; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) { const float d = v[i][j][q] - mean[i]; sacc += d * d; }
+                            rowstat[r] = sacc;
+                        }
+                    }
+                    __syncthreads();
+                    for (int q = tid; q < nb * ng; q += 256) {
+                        const float *rp = rowstat + (q / ng) * cc + (q % ng) * gs;
+                        float sacc = 0.f;
+                        for (int j = 0; j < gs; ++j) sacc += rp[j];
+                        gstat[q] = 1.f / sqrtf(sacc * inv_cnt + 1e-5f);
+                    }
+                    __syncthreads();
+                    float rstd[RPT];
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + 256 * i;
+                        rstd[i] = (r < rows) ? gstat[rb[i] * ng + rc[i] / gs] : 0.f;
+                    }
+                    __syncthreads();      // exchange arrays are dead: the slab may be written now
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + 256 * i;
+                        const int cg = c0 + rc[i];
+                        if (r < rows && cg < S.C) {
+                            const float ga = S.gamma[cg] * rstd[i], be = S.beta[cg];
+#pragma unroll
+                            for (int j = 0; j < LV; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    float w = (v[i][j][q] - mean[i]) * ga + be;
+                                    if (S.act) w = silu(w);
+                                    v[i][j][q] = w;
+                                }
+                        }
+                    }
+                } else if (S.act) {
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i)
+#pragma unroll
+                        for (int j = 0; j < LV; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[i][j][q] = silu(v[i][j][q]);
+                }
+                // ---- write the slab, transposed to [b][position][channel] ---------------------------------
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = tid + 256 * i;
+                    if (r < rows) {
+                        float *dst = lds + (rb[i] * A.Lsl + pad) * cs + rc[i];
+#pragma unroll
+                        for (int j = 0; j < LV; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int l = 4 * j + q;
+                                if (S.ups) { dst[(2 * l) * cs] = v[i][j][q]; dst[(2 * l + 1) * cs] = v[i][j][q]; }
+                                else dst[l * cs] = v[i][j][q];
+                            }
+                    }
+                }
+                // zero halo: positions outside [pad, pad + Lcov)
+                const int nz = A.Lsl - Lcov;
+                for (int e = tid; e < rows * nz; e += 256) {
+                    const int r = e / nz, z = e % nz;
+                    const int p = z < pad ? z : Lcov + z;
+                    lds[((r / cc) * A.Lsl + p) * cs + (r % cc)] = 0.f;
+                }
+                __syncthreads();
             }
-            // ---- MFMA over (tap, 8-channel group) -----------------------------------------------
+            // ---- MFMA over (tap, 8-channel group); weight fragments prefetched one stage ahead ------------
             if (active) {
                 const int nkg = cc >> 3;
                 const int iters = S.taps * nkg;
-                for (int it = kpart; it < iters; it += KP) {
-                    const int tap = it / nkg, kgi = it % nkg;
-                    const f32x4 a = wbase[(size_t)(S.kg_off + tap * kgs_per_tap + (c0 >> 3) + kgi) * 64];
+                const int ngroups = (iters + CONV_U - 1) / CONV_U;
+                const int wk0 = S.kg_off + (c0 >> 3);
+                f32x4 a_cur[CONV_U], a_nxt[CONV_U];
+                int g = kpart;
+                if (g < ngroups) {
 #pragma unroll
-                    for (int i = 0; i < CONV_CT_MAX; ++i) {
-                        if (ct0 + i * ct_step < nct) {
-                            const float *src = lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5));
-                            const f32x4 b = *reinterpret_cast<const f32x4 *>(src);
+                    for (int u = 0; u < CONV_U; ++u) {
+                        const int it = min(g * CONV_U + u, iters - 1);
+                        a_cur[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
+                    }
+                }
+                for (; g < ngroups; g += KP) {
+                    const int gnx = g + KP;
+                    if (gnx < ngroups) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc[i], 0, 0, 0);
+                        for (int u = 0; u < CONV_U; ++u) {
+                            const int it = min(gnx * CONV_U + u, iters - 1);
+                            a_nxt[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
                         }
                     }
+#pragma unroll
+                    for (int u = 0; u < CONV_U; ++u) {
+                        const int it = g * CONV_U + u;
+                        if (it < iters) {
+                            const int tap = it / nkg, kgi = it % nkg;
+#pragma unroll
+                            for (int i = 0; i < CONV_CT_MAX; ++i) {
+                                if (ct0 + i * ct_step < nct) {
+                                    const float *src = lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5));
+                                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][q], bq[q], acc[i], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < CONV_U; ++u) a_cur[u] = a_nxt[u];
                 }
             }
         }
@@ -198,6 +346,53 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                 const float *srcp = red + ((size_t)(kp - 1) * nct + ct0) * 1024;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] += srcp[r * 64 + lane];
+            }
+        }
+    }
+    // ---- cross-workgroup K reduction: every slice publishes its partial tiles; the last arriver
+    //      sums them in slice order (deterministic) and runs the epilogue.  Publication follows the
+    //      agent-scope release / acquire recipe (cdna_hip_programming.md §6 G16): plain stores ->
+    //      vmcnt(0) -> barrier -> one-lane release fence -> relaxed ticket; last arriver: acquire.
+    if (A.KS > 1) {
+        const size_t slot = ((size_t)blockIdx.y * gridDim.x + tile);
+        float *mine = A.part + (((size_t)kz * gridDim.y + blockIdx.y) * gridDim.x + tile) * A.part_stride;
+        if (active && kpart == 0) {
+#pragma unroll
+            for (int i = 0; i < CONV_CT_MAX; ++i) {
+                const int ct = ct0 + i * ct_step;
+                if (ct < nct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[(ct * 16 + r) * 64 + lane] = acc[i][r];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *flag = reinterpret_cast<int *>(red + 6 * 1024 - 4);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (prev == A.KS - 1) ? 1 : 0;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(A.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        if (active && kpart == 0) {
+#pragma unroll
+            for (int i = 0; i < CONV_CT_MAX; ++i) {
+                const int ct = ct0 + i * ct_step;
+                if (ct >= nct) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                for (int z = 0; z < A.KS; ++z) {
+                    const float *src = A.part + (((size_t)z * gridDim.y + blockIdx.y) * gridDim.x + tile) * A.part_stride;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] += src[(ct * 16 + r) * 64 + lane];
+                }
             }
         }
     }
@@ -353,6 +548,8 @@ struct surfd_unet {
     std::vector<float *> buf_ptr; int ws_B = 0, ws_L = 0;
     float *temb = nullptr, *h1 = nullptr, *emb = nullptr, *emb_table = nullptr; int emb_rows_cap = 0; int emb_rows = 0, emb_B = 0;
     int64_t *t_dev = nullptr; int t_cap = 0;
+    float *part = nullptr; size_t part_floats = 0;     // split-K partial tiles
+    int *counters = nullptr;
 };
 
 namespace {
@@ -631,8 +828,17 @@ int unet_alloc(surfd_unet *u) {
     HIP_TRY(hipMemset(u->vecs, 0, voff * sizeof(float)));
     if (u->cfg.num_classes > 0) HIP_TRY(hipMalloc((void **)&u->label_table, (size_t)u->cfg.num_classes * u->ted * sizeof(float)));
     const int max_lds = 160 * 1024;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    u->part_floats = (size_t)16 << 20;                      // 64 MB of partial tiles
+    HIP_TRY(hipMalloc((void **)&u->part, u->part_floats * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&u->counters, 8192 * sizeof(int)));
+    HIP_TRY(hipMemset(u->counters, 0, 8192 * sizeof(int)));
     u->allocated = true;
     return SURFD_OK;
 }
@@ -683,6 +889,8 @@ void surfd_unet_destroy(surfd_unet *u) {
     for (float *p : u->buf_ptr) if (p) (void)hipFree(p);
     for (float *p : {u->temb, u->h1, u->emb, u->emb_table}) if (p) (void)hipFree(p);
     if (u->t_dev) (void)hipFree(u->t_dev);
+    if (u->part) (void)hipFree(u->part);
+    if (u->counters) (void)hipFree(u->counters);
     delete u;
 }
 
@@ -839,21 +1047,51 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     };
     int need = 8;
     for (int s = 0; s < c.nseg; ++s) need = std::max(need, min_cc(c.seg[s]));
+    const int Lin0 = A.seg[0].Lin;
+    for (int s = 1; s < c.nseg; ++s)
+        if (A.seg[s].Lin != Lin0) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: segments with different operand lengths");
+    int log2lv = -2;
+    switch (Lin0) { case 1: log2lv = -1; break; case 4: log2lv = 0; break; case 8: log2lv = 1; break;
+                    case 16: log2lv = 2; break; case 32: log2lv = 3; break; case 64: log2lv = 4; break; }
+    if (log2lv == -2) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand length %d (supported: 1, 4, 8, 16, 32, 64)", Lin0);
+    // a thread stages at most CONV_VEC_MAX float4 in registers: nb * cc * Lin <= 256 * 128 floats
+    const long reg_cap = 256L * CONV_VEC_MAX * 4;
+    auto fits = [&](int bc, int cc) {
+        return (long)bc * A.Lsl * (cc + 4) <= budget && (long)bc * cc * Lin0 <= reg_cap;
+    };
     int bchunk = std::min(B, std::max(1, 512 / A.Lout));
-    while (bchunk > 1 && (long)bchunk * A.Lsl * (need + 4) > budget) --bchunk;
-    if ((long)bchunk * A.Lsl * (need + 4) > 36000)
-        SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand does not fit LDS (L=%d, C=%d)", L, c.seg[0].C);
+    while (bchunk > 1 && !fits(bchunk, need)) --bchunk;
+    if (!fits(bchunk, need))
+        SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand does not fit LDS/registers (L=%d, C=%d)", L, c.seg[0].C);
+    // more, smaller workgroups while the chip is under-filled (weights are then re-read through L2)
+    const int ntiles = ceil_div(c.Cout, 32);
+    while (bchunk > 1 && ntiles * ceil_div(B, bchunk) < 128 && ((bchunk + 1) / 2) * A.Lout >= 32) bchunk = (bchunk + 1) / 2;
     A.bchunk = bchunk;
-    int cs_max = 0;
+    // split K over workgroups when (channel tiles x batch chunks) cannot fill the chip: the heavy
+    // low-resolution layers have 28 channel tiles and ONE batch chunk but stream 19 MB of weights
+    const int nby = ceil_div(B, bchunk);
+    int ks_target = 1;
+    if (ntiles * nby < 192) ks_target = std::min(16, ceil_div(256, ntiles * nby));
+    long work = 0;
+    for (int s = 0; s < c.nseg; ++s) work += (long)c.seg[s].taps * (ceil_div(c.seg[s].C, 8) * 8);
+    const long work_per_slice = ceil_div<long>(work, ks_target);
+    int cs_max = 0, nchunks = 0;
     for (int s = 0; s < c.nseg; ++s) {
         const SegPlan &sp = c.seg[s];
         const int unit = min_cc(sp);
         const int Cp = ceil_div(sp.C, 8) * 8;
-        int cc_cap = (int)(budget / ((long)bchunk * A.Lsl)) - 4;
-        int cc = std::max(unit, (cc_cap / unit) * unit);
-        cc = std::min(cc, ceil_div(Cp, unit) * unit);
+        int cc = std::min(ceil_div(Cp, unit) * unit, 4096);
+        if (ks_target > 1) cc = std::min<long>(cc, std::max<long>(unit, ceil_div<long>(ceil_div<long>(work_per_slice, sp.taps), unit) * unit));
+        while (cc > unit && !fits(bchunk, cc)) cc -= unit;
         A.seg[s].cc = cc;
+        nchunks += ceil_div(Cp, cc);
         cs_max = std::max(cs_max, cc + 4);
+    }
+    A.KS = std::max(1, std::min(ks_target, nchunks));
+    A.part_stride = ceil_div(bchunk * A.Lout, 32) * 1024;
+    if (A.KS > 1) {
+        if ((size_t)A.KS * nby * ntiles * A.part_stride > u->part_floats || nby * ntiles > 8192) A.KS = 1;
+        A.part = u->part; A.counters = u->counters;
     }
     A.cs_max = cs_max;
     if (c.emb_off >= 0 && emb) { A.emb = emb + c.emb_off; A.emb_bstride = emb_bs; }
@@ -861,8 +1099,15 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     const Resolved o = resolve(c.dst, c.ds_out, 0, true);
     A.out = o.ptr; A.out_bstride = o.bstride;
     const size_t lds_bytes = ((size_t)bchunk * A.Lsl * cs_max + 3 * 1024 * 2) * sizeof(float);
-    dim3 grid(ceil_div(c.Cout, 32), ceil_div(B, bchunk));
-    hipLaunchKernelGGL(conv_kernel, grid, dim3(256), lds_bytes, st, A);
+    dim3 grid(ceil_div(c.Cout, 32), ceil_div(B, bchunk), A.KS);
+    switch (log2lv) {
+        case -1: hipLaunchKernelGGL(conv_kernel<-1>, grid, dim3(256), lds_bytes, st, A); break;
+        case 0: hipLaunchKernelGGL(conv_kernel<0>, grid, dim3(256), lds_bytes, st, A); break;
+        case 1: hipLaunchKernelGGL(conv_kernel<1>, grid, dim3(256), lds_bytes, st, A); break;
+        case 2: hipLaunchKernelGGL(conv_kernel<2>, grid, dim3(256), lds_bytes, st, A); break;
+        case 3: hipLaunchKernelGGL(conv_kernel<3>, grid, dim3(256), lds_bytes, st, A); break;
+        default: hipLaunchKernelGGL(conv_kernel<4>, grid, dim3(256), lds_bytes, st, A); break;
+    }
     LAUNCH_CHECK();
     return SURFD_OK;
 }
