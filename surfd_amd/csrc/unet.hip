@@ -77,7 +77,8 @@ __device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
 //               row per thread as LV float4 loads issued back to back;
 // LOG2_LV < 0 : length-1 operands (the Linear layers of the embedding path), staged as float4
 //               along the channel axis.
-template <int LOG2_LV>
+// PARTIAL     : rows shorter than one float4 (Lin = 1 or 2 at the deepest levels of short latents).
+template <int LOG2_LV, bool PARTIAL = false>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     constexpr bool LIN1 = LOG2_LV < 0;
     constexpr int LV = LIN1 ? 1 : (1 << LOG2_LV);
@@ -173,9 +174,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     const bool ok = r < rows && cg < S.C;
                     int bs = b0 + rb[i];
                     if (S.bmod) bs %= S.bmod;
-                    const f32x4 *src = reinterpret_cast<const f32x4 *>(S.x + bs * S.bstride + (long)cg * S.Lin);
+                    if constexpr (PARTIAL) {
+                        const float *src1 = S.x + bs * S.bstride + (long)cg * S.Lin;
 #pragma unroll
-                    for (int j = 0; j < LV; ++j) v[i][j] = ok ? src[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int q = 0; q < 4; ++q) v[i][0][q] = (ok && q < S.Lin) ? src1[q] : 0.f;
+                    } else {
+                        const f32x4 *src = reinterpret_cast<const f32x4 *>(S.x + bs * S.bstride + (long)cg * S.Lin);
+#pragma unroll
+                        for (int j = 0; j < LV; ++j) v[i][j] = ok ? src[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
                 if (S.gn) {
                     // two-pass GroupNorm statistics without leaving the register file; the small
@@ -217,7 +224,10 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
 #pragma unroll
                             for (int j = 0; j < LV; ++j)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) { const float d = v[i][j][q] - mean[i]; sacc += d * d; }
+                                for (int q = 0; q < 4; ++q) {
+                                    const float d = v[i][j][q] - mean[i];
+                                    if (!PARTIAL || 4 * j + q < S.Lin) sacc += d * d;
+                                }
                             rowstat[r] = sacc;
                         }
                     }
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const int l = 4 * j + q;
+                                if (PARTIAL && l >= S.Lin) continue;
                                 if (S.ups) { dst[(2 * l) * cs] = v[i][j][q]; dst[(2 * l + 1) * cs] = v[i][j][q]; }
                                 else dst[l * cs] = v[i][j][q];
                             }
@@ -830,6 +841,7 @@ int unet_alloc(surfd_unet *u) {
     const int max_lds = 160 * 1024;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -1051,13 +1063,15 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     for (int s = 1; s < c.nseg; ++s)
         if (A.seg[s].Lin != Lin0) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: segments with different operand lengths");
     int log2lv = -2;
-    switch (Lin0) { case 1: log2lv = -1; break; case 4: log2lv = 0; break; case 8: log2lv = 1; break;
-                    case 16: log2lv = 2; break; case 32: log2lv = 3; break; case 64: log2lv = 4; break; }
-    if (log2lv == -2) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand length %d (supported: 1, 4, 8, 16, 32, 64)", Lin0);
+    const bool linear = c.seg[0].ds == 0;                      // embedding-path Linear layers
+    switch (Lin0) { case 1: log2lv = linear ? -1 : 5; break; case 2: log2lv = 5; break; case 4: log2lv = 0; break;
+                    case 8: log2lv = 1; break; case 16: log2lv = 2; break; case 32: log2lv = 3; break; case 64: log2lv = 4; break; }
+    if (log2lv == -2) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand length %d (supported: 1, 2, 4, 8, 16, 32, 64)", Lin0);
+    const int lin_regs = std::max(Lin0, 4);
     // a thread stages at most CONV_VEC_MAX float4 in registers: nb * cc * Lin <= 256 * 128 floats
     const long reg_cap = 256L * CONV_VEC_MAX * 4;
     auto fits = [&](int bc, int cc) {
-        return (long)bc * A.Lsl * (cc + 4) <= budget && (long)bc * cc * Lin0 <= reg_cap;
+        return (long)bc * A.Lsl * (cc + 4) <= budget && (long)bc * cc * lin_regs <= reg_cap;
     };
     int bchunk = std::min(B, std::max(1, 512 / A.Lout));
     while (bchunk > 1 && !fits(bchunk, need)) --bchunk;
@@ -1071,9 +1085,11 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     // low-resolution layers have 28 channel tiles and ONE batch chunk but stream 19 MB of weights
     const int nby = ceil_div(B, bchunk);
     int ks_target = 1;
-    if (ntiles * nby < 192) ks_target = std::min(16, ceil_div(256, ntiles * nby));
     long work = 0;
     for (int s = 0; s < c.nseg; ++s) work += (long)c.seg[s].taps * (ceil_div(c.seg[s].C, 8) * 8);
+    // the publish/acquire hand-off costs ~8 us: only worth it when a workgroup would otherwise stream
+    // more than ~192 KB of weights on its own
+    if (ntiles * nby < 192 && work * 128 > 192 * 1024) ks_target = std::min(16, ceil_div(256, ntiles * nby));
     const long work_per_slice = ceil_div<long>(work, ks_target);
     int cs_max = 0, nchunks = 0;
     for (int s = 0; s < c.nseg; ++s) {
@@ -1106,6 +1122,7 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         case 1: hipLaunchKernelGGL(conv_kernel<1>, grid, dim3(256), lds_bytes, st, A); break;
         case 2: hipLaunchKernelGGL(conv_kernel<2>, grid, dim3(256), lds_bytes, st, A); break;
         case 3: hipLaunchKernelGGL(conv_kernel<3>, grid, dim3(256), lds_bytes, st, A); break;
+        case 5: hipLaunchKernelGGL((conv_kernel<0, true>), grid, dim3(256), lds_bytes, st, A); break;
         default: hipLaunchKernelGGL(conv_kernel<4>, grid, dim3(256), lds_bytes, st, A); break;
     }
     LAUNCH_CHECK();
@@ -1187,7 +1204,7 @@ int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, i
     if (row0 < 0 || row0 + B > u->emb_rows) SURFD_FAIL(SURFD_ERR_STATE, "unet: embedding rows [%d,%d) not prepared", row0, row0 + B);
     int max_ds = 1;
     for (auto &b : u->bufs) max_ds = std::max(max_ds, b.ds);
-    if (L % max_ds || L < max_ds || L > 64) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "unet: latent length %d must be a multiple of %d and <= 64", L, max_ds);
+    if (L % max_ds || L < max_ds || L > 64 || (L & (L - 1))) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "unet: latent length %d must be a power of two in [%d, 64]", L, max_ds);
     int rc = ensure_workspace(u, B, L);
     if (rc) return rc;
     const float *emb = u->emb_table + (size_t)row0 * u->emb_total;
