@@ -1,0 +1,81 @@
+"""Multi-GPU sampling: shapes are independent (no cross-sample op anywhere in the reverse loop or
+the decoder — SURVEY.md §8e), so every rank owns a contiguous block of global shape indices for
+BOTH the reverse loop and the grids, with replicated weights and no collective on the data path.
+Noise (and conditioning) is seeded per *global* shape index, which makes a shape's result
+independent of the world size.  The only collective is an optional all_gather of the final
+latents ([B,1,L] floats — a few KB) over RCCL/xGMI (backend "nccl") or gloo (CPU tests).
+
+The reference has no multi-GPU sampling path (utils/dist_util.py:18-41 is a stub).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+
+def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """(first, count) of the contiguous block owned by `rank`; the remainder goes to the first ranks."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(total, world)
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(world, rank, local_rank) from the torchrun environment; initialises the process group
+    when world > 1 (backend default: nccl == RCCL when a GPU is present, else gloo)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            dist.init_process_group(backend=backend)
+    return world, rank, local
+
+
+def gather_latents(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
+    """all_gather of per-rank latent blocks with (possibly) different lengths -> [sum(counts), ...]
+    in global shape order.  Single-process: identity."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    assert len(counts) == world
+    m = max(counts)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+
+
+def sample_sharded(diffusion, model, total: int, latent_len: int, sampler: str = "ddpm", seed: int = 1234,
+                   model_kwargs_fn=None, gather: bool = True, **loop_kwargs):
+    """Runs the reverse loop for this rank's block of `total` shapes and (optionally) gathers all
+    latents.  ``model_kwargs_fn(first, count)`` builds the per-block conditioning (default: {'y': {}})."""
+    from . import synth
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    first, count = shard_range(total, world, rank)
+    device = next(model.parameters()).device if hasattr(model, "parameters") else torch.device("cpu")
+    T = diffusion.num_timesteps
+    noise = synth.synth_noise_batch(T, first, count, latent_len, seed).to(device) if count else None
+    lat = torch.zeros(0, 1, latent_len, device=device)
+    if count:
+        kw = model_kwargs_fn(first, count) if model_kwargs_fn else {"y": {}}
+        fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
+        lat = fn(model, (count, 1, latent_len), clip_denoised=False, model_kwargs=kw, noise_stream=noise, device=device,
+                 **loop_kwargs)
+    if gather and world > 1:
+        counts = [shard_range(total, world, r)[1] for r in range(world)]
+        return gather_latents(lat, counts), (first, count)
+    return lat, (first, count)

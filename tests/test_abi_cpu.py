@@ -1,0 +1,111 @@
+"""CPU-only checks of the C-ABI boundary: the library builds/loads without a GPU, exports every
+symbol include/surfd_hip.h declares, enumerates the reference checkpoint layouts, and reports
+errors through return codes (never by falling back to a CPU computation)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from surfd_amd import _native as N
+from surfd_amd.spec import DecoderConfig, UNetConfig, decoder_param_spec, unet_param_spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(N.LIB_PATH):
+        from surfd_amd.build import build_library
+        build_library()
+    return N.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "surfd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(surfd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    raw = C.CDLL(N.LIB_PATH)
+    for sym in declared:
+        assert hasattr(raw, sym), f"{sym} declared in surfd_hip.h but not exported"
+    assert set(N.EXPORTED_SYMBOLS) == set(declared), set(N.EXPORTED_SYMBOLS) ^ set(declared)
+
+
+def test_version_and_no_device(lib):
+    assert lib.surfd_abi_version() == 1
+    assert lib.surfd_device_count() >= 0
+
+
+def _unet_cfg(ncls=0, mult=(1, 2, 4, 4)):
+    return N.UNetCfg(1, 224, 1, 2, len(mult), (C.c_int * 8)(*mult), 3, (C.c_int * 8)(4, 2, 1), 8, 512, ncls)
+
+
+@pytest.mark.parametrize("ncls", [0, 9])
+def test_unet_plan_matches_checkpoint_layout(lib, ncls):
+    h = C.c_void_p()
+    N.check(lib.surfd_unet_create(C.byref(_unet_cfg(ncls)), C.byref(h)))
+    got = []
+    for i in range(lib.surfd_unet_num_params(h)):
+        key, shp, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        N.check(lib.surfd_unet_param_info(h, i, C.byref(key), shp, C.byref(nd)))
+        got.append(("Unet." + key.value.decode(), tuple(shp[:nd.value])))
+    assert got == unet_param_spec(UNetConfig(num_classes=ncls or None))
+    lib.surfd_unet_destroy(h)
+
+
+@pytest.mark.parametrize("D", [32, 64])
+def test_decoder_layout(lib, D):
+    h = C.c_void_p()
+    N.check(lib.surfd_decoder_create(63, D, 512, 5, C.byref(h)))
+    got = []
+    for i in range(lib.surfd_decoder_num_params(h)):
+        key, shp, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        N.check(lib.surfd_decoder_param_info(h, i, C.byref(key), shp, C.byref(nd)))
+        got.append((key.value.decode(), tuple(shp[:nd.value])))
+    assert got == decoder_param_spec(DecoderConfig(latent_dim=D))
+    lib.surfd_decoder_destroy(h)
+
+
+def test_errors_are_return_codes(lib):
+    h = C.c_void_p()
+    rc = lib.surfd_decoder_create(63, 32, 256, 5, C.byref(h))          # hidden_dim the kernels are not built for
+    assert rc == -4 and b"512" in lib.surfd_last_error()
+    rc = lib.surfd_grid_create(100, C.byref(h))                          # not a power of two
+    assert rc == -4
+    bad = _unet_cfg()
+    bad.model_channels = 100
+    assert lib.surfd_unet_create(C.byref(bad), C.byref(h)) == -4
+    with pytest.raises(RuntimeError, match="libsurfd_hip error"):
+        N.check(lib.surfd_unet_create(None, C.byref(h)))
+    # a grid handle without thresholds refuses to run (state error), nothing is computed on the host
+    g = C.c_void_p()
+    N.check(lib.surfd_grid_create(64, C.byref(g)))
+    assert lib.surfd_grid_begin(g, None, None, None) == -2
+    lib.surfd_grid_destroy(g)
+
+
+def test_product_modules_refuse_cpu():
+    """No CPU fallback: the drop-in modules raise on CPU tensors instead of computing."""
+    from surfd_amd.cbndec import CbnDecoder, CoordsEncoder
+    from surfd_amd.mdm import MDM
+    dec = CbnDecoder(63, 32, 512, 5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(CoordsEncoder().encode(torch.zeros(1, 4, 3)), torch.zeros(1, 32))
+    m = MDM(cond_mode="no_cond", unet_cfg=UNetConfig(channel_mult=(1,), num_res_blocks=1, attention_resolutions=()))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 32), torch.zeros(1, dtype=torch.long), y={})
+
+
+def test_no_product_import_of_oracle():
+    pkg = os.path.join(ROOT, "surfd_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
