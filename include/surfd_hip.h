@@ -48,6 +48,9 @@ int surfd_device_count(void);
  * 1 = decoder forward+reverse kernel, 2 = whole surfd_sample_loop.  read is host-sync and clears. */
 int surfd_profile_enable(int on);
 int surfd_profile_read(int kind, int64_t *launches, double *total_ms);
+/* developer aid: with SURFD_CONV_DEBUG=1 in the environment every conv launch records shader-clock
+ * stamps of its phases (16 int64 per launch); host-sync read + reset, returns the launch count */
+int surfd_unet_debug_read(surfd_unet *u, long long *out, int max_launches);
 
 /* ------------------------------------------------------------------------------------ */
 /* Denoiser: UNetModel (models/openaimodel.py:413-749) as configured by MDM             */

@@ -43,6 +43,7 @@ _SIGS = {
     "surfd_device_count": (C.c_int, []),
     "surfd_profile_enable": (C.c_int, [C.c_int]),
     "surfd_profile_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),
+    "surfd_unet_debug_read": (C.c_int, [_P, C.POINTER(C.c_longlong), C.c_int]),
     "surfd_unet_create": (C.c_int, [C.POINTER(UNetCfg), C.POINTER(_P)]),
     "surfd_unet_destroy": (None, [_P]),
     "surfd_unet_num_params": (C.c_int, [_P]),

@@ -60,15 +60,17 @@ struct ConvArgs {
     int bchunk;            // batch entries per workgroup
     int Lsl;               // staged positions per batch entry
     int cs_max;            // LDS row stride of the largest chunk (floats)
+    int red_off;           // float offset of the reduction scratch behind the slab / GN exchange area
     // cross-workgroup split-K (blockIdx.z = K slice): partial accumulators + arrival counters
     int KS;
     float *part;           // [KS][gridDim.y][gridDim.x][part_stride]
     int part_stride;       // floats per partial tile set (column tiles x 1024)
     int *counters;         // [gridDim.y][gridDim.x], zero between launches
+    long long *dbg;        // optional: phase timestamps of workgroup (0,0,last slice), 16 slots
 };
 
 constexpr int CONV_CT_MAX = 4;   // column tiles (32 output positions each) per wave
-constexpr int CONV_VEC_MAX = 32;  // float4 registers a thread may hold while staging (128 floats)
+constexpr int CONV_VEC_MAX = 16;  // float4 registers a thread may hold while staging (64 floats)
 constexpr int CONV_U = 8;         // weight fragments fetched per software-pipeline stage
 
 __device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
@@ -113,9 +115,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
         coll[i] = m % A.Lout;
     }
     const f32x4 *wbase = reinterpret_cast<const f32x4 *>(A.wp) + (size_t)tile * A.KGtot * 64 + lane;
-    float *red = lds + (size_t)A.bchunk * A.Lsl * A.cs_max;   // cross-wave K reduction scratch
+    float *red = lds + A.red_off;   // cross-wave K reduction scratch
     const int kz = blockIdx.z;
     int chunk_id = 0;
+    const bool dbg_on = A.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#define DBG_STAMP(slot) do { if (dbg_on) A.dbg[(slot)] = (long long)clock64(); } while (0)
+    DBG_STAMP(0);
 
     for (int si = 0; si < A.nseg; ++si) {
         const SegArgs S = A.seg[si];
@@ -127,7 +132,22 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             if ((chunk_id++) % A.KS != kz) continue;          // K slices are dealt round-robin by chunk
             const int cc = min(S.cc, S.Cp - c0);
             const int cs = cc + 4;
+            // first weight fragments of this chunk: requested before the operand is staged so the
+            // HBM/MALL latency overlaps the staging + GroupNorm phase
+            const int nkg = cc >> 3;
+            const int iters = S.taps * nkg;
+            const int ngroups = (iters + CONV_U - 1) / CONV_U;
+            const int wk0 = S.kg_off + (c0 >> 3);
+            f32x4 a_cur[CONV_U], a_nxt[CONV_U];
+            if (active && kpart < ngroups) {
+#pragma unroll
+                for (int u = 0; u < CONV_U; ++u) {
+                    const int it = min(kpart * CONV_U + u, iters - 1);
+                    a_cur[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
+                }
+            }
             __syncthreads();   // previous chunk's MFMA reads are done
+            DBG_STAMP(1);
             if constexpr (LIN1) {
                 // ---- length-1 operand: float4 along channels -------------------------------------
                 const int vpr = cc >> 2;                      // vectors per batch row
@@ -185,12 +205,23 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     }
                 }
                 if (S.gn) {
+                    if (dbg_on) { asm volatile("" :: "v"(v[0][0][0])); DBG_STAMP(2); }
                     // two-pass GroupNorm statistics without leaving the register file; the small
-                    // exchange arrays alias the (not yet written) slab
-                    float *rowstat = lds;                 // [rows]
-                    float *gstat = lds + rows;            // [nb * ng]
+                    // exchange arrays alias the (not yet written) slab.  gamma/beta are requested
+                    // now, consumed after the statistics.
+                    float ga[RPT], be[RPT];
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int cg = min(c0 + rc[i], S.C - 1);
+                        ga[i] = S.gamma[cg]; be[i] = S.beta[cg];
+                    }
+                    float *rowmean = lds;                 // [rows]
+                    float *rowm2 = lds + rows;            // [rows]
+                    float *gstat = lds + 2 * rows;        // [nb * ng][2]
                     const int ng = cc / gs;
+                    const float inv_len = 1.f / (float)S.Lin;
                     const float inv_cnt = 1.f / (float)(gs * S.Lin);
+                    // per-row mean and centred second moment, two-pass inside the register file
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
                         const int r = tid + 256 * i;
@@ -198,65 +229,50 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                             float sacc = 0.f;
 #pragma unroll
                             for (int j = 0; j < LV; ++j) sacc += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
-                            rowstat[r] = sacc;
-                        }
-                    }
-                    __syncthreads();
-                    for (int q = tid; q < nb * ng; q += 256) {
-                        const float *rp = rowstat + (q / ng) * cc + (q % ng) * gs;
-                        float sacc = 0.f;
-                        for (int j = 0; j < gs; ++j) sacc += rp[j];
-                        gstat[q] = sacc * inv_cnt;
-                    }
-                    __syncthreads();
-                    float mean[RPT];
-#pragma unroll
-                    for (int i = 0; i < RPT; ++i) {
-                        const int r = tid + 256 * i;
-                        mean[i] = (r < rows) ? gstat[rb[i] * ng + rc[i] / gs] : 0.f;
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < RPT; ++i) {
-                        const int r = tid + 256 * i;
-                        if (r < rows) {
-                            float sacc = 0.f;
+                            const float rm = sacc * inv_len;
+                            float m2 = 0.f;
 #pragma unroll
                             for (int j = 0; j < LV; ++j)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    const float d = v[i][j][q] - mean[i];
-                                    if (!PARTIAL || 4 * j + q < S.Lin) sacc += d * d;
+                                    const float d = v[i][j][q] - rm;
+                                    if (!PARTIAL || 4 * j + q < S.Lin) m2 += d * d;
                                 }
-                            rowstat[r] = sacc;
+                            rowmean[r] = rm; rowm2[r] = m2;
                         }
                     }
                     __syncthreads();
+                    // group statistics: equal-size rows combine exactly (Chan et al.):
+                    //   mean = avg(row means),  M2 = sum(row M2) + Lin * sum((row mean - mean)^2)
                     for (int q = tid; q < nb * ng; q += 256) {
-                        const float *rp = rowstat + (q / ng) * cc + (q % ng) * gs;
-                        float sacc = 0.f;
-                        for (int j = 0; j < gs; ++j) sacc += rp[j];
-                        gstat[q] = 1.f / sqrtf(sacc * inv_cnt + 1e-5f);
+                        const int off = (q / ng) * cc + (q % ng) * gs;
+                        float sm = 0.f;
+                        for (int j = 0; j < gs; ++j) sm += rowmean[off + j];
+                        const float gm = sm / (float)gs;
+                        float m2 = 0.f, dev = 0.f;
+                        for (int j = 0; j < gs; ++j) { m2 += rowm2[off + j]; const float d = rowmean[off + j] - gm; dev += d * d; }
+                        gstat[2 * q] = gm;
+                        gstat[2 * q + 1] = 1.f / sqrtf((m2 + (float)S.Lin * dev) * inv_cnt + 1e-5f);
                     }
                     __syncthreads();
-                    float rstd[RPT];
+                    float scal[RPT], gmean[RPT];
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
                         const int r = tid + 256 * i;
-                        rstd[i] = (r < rows) ? gstat[rb[i] * ng + rc[i] / gs] : 0.f;
+                        const int q = (r < rows) ? rb[i] * ng + rc[i] / gs : 0;
+                        gmean[i] = gstat[2 * q]; scal[i] = gstat[2 * q + 1];
                     }
                     __syncthreads();      // exchange arrays are dead: the slab may be written now
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
                         const int r = tid + 256 * i;
-                        const int cg = c0 + rc[i];
-                        if (r < rows && cg < S.C) {
-                            const float ga = S.gamma[cg] * rstd[i], be = S.beta[cg];
+                        if (r < rows && c0 + rc[i] < S.C) {
+                            const float gsc = ga[i] * scal[i];
 #pragma unroll
                             for (int j = 0; j < LV; ++j)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    float w = (v[i][j][q] - mean[i]) * ga + be;
+                                    float w = (v[i][j][q] - gmean[i]) * gsc + be[i];
                                     if (S.act) w = silu(w);
                                     v[i][j][q] = w;
                                 }
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[i][j][q] = silu(v[i][j][q]);
                 }
+                DBG_STAMP(3);
                 // ---- write the slab, transposed to [b][position][channel] ---------------------------------
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
@@ -296,21 +313,10 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                 }
                 __syncthreads();
             }
+            DBG_STAMP(4);
             // ---- MFMA over (tap, 8-channel group); weight fragments prefetched one stage ahead ------------
             if (active) {
-                const int nkg = cc >> 3;
-                const int iters = S.taps * nkg;
-                const int ngroups = (iters + CONV_U - 1) / CONV_U;
-                const int wk0 = S.kg_off + (c0 >> 3);
-                f32x4 a_cur[CONV_U], a_nxt[CONV_U];
                 int g = kpart;
-                if (g < ngroups) {
-#pragma unroll
-                    for (int u = 0; u < CONV_U; ++u) {
-                        const int it = min(g * CONV_U + u, iters - 1);
-                        a_cur[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
-                    }
-                }
                 for (; g < ngroups; g += KP) {
                     const int gnx = g + KP;
                     if (gnx < ngroups) {
@@ -320,22 +326,37 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                             a_nxt[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
                         }
                     }
+                    // operand fragments are fetched one iteration ahead of the MFMAs that consume them
+                    f32x4 bq[CONV_CT_MAX], bn[CONV_CT_MAX];
+                    {
+                        const int it = min(g * CONV_U, iters - 1);
+                        const int tap = it / nkg, kgi = it % nkg;
+#pragma unroll
+                        for (int i = 0; i < CONV_CT_MAX; ++i)
+                            bq[i] = *reinterpret_cast<const f32x4 *>(lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5)));
+                    }
 #pragma unroll
                     for (int u = 0; u < CONV_U; ++u) {
                         const int it = g * CONV_U + u;
+                        {
+                            const int itn = min(it + 1, iters - 1);
+                            const int tap = itn / nkg, kgi = itn % nkg;
+#pragma unroll
+                            for (int i = 0; i < CONV_CT_MAX; ++i)
+                                bn[i] = *reinterpret_cast<const f32x4 *>(lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5)));
+                        }
                         if (it < iters) {
-                            const int tap = it / nkg, kgi = it % nkg;
 #pragma unroll
                             for (int i = 0; i < CONV_CT_MAX; ++i) {
                                 if (ct0 + i * ct_step < nct) {
-                                    const float *src = lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5));
-                                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
                                     for (int q = 0; q < 4; ++q)
-                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][q], bq[q], acc[i], 0, 0, 0);
+                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][q], bq[i][q], acc[i], 0, 0, 0);
                                 }
                             }
                         }
+#pragma unroll
+                        for (int i = 0; i < CONV_CT_MAX; ++i) bq[i] = bn[i];
                     }
 #pragma unroll
                     for (int u = 0; u < CONV_U; ++u) a_cur[u] = a_nxt[u];
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             }
         }
     }
+    DBG_STAMP(5);
     // ---- cross-wave K reduction (only when spare waves split K) --------------------------------
     if (KP > 1) {
         __syncthreads();
@@ -360,6 +382,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             }
         }
     }
+    DBG_STAMP(6);
     // ---- cross-workgroup K reduction: every slice publishes its partial tiles; the last arriver
     //      sums them in slice order (deterministic) and runs the epilogue.  Publication follows the
     //      agent-scope release / acquire recipe (cdna_hip_programming.md §6 G16): plain stores ->
@@ -391,6 +414,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             *flag = last;
         }
         __syncthreads();
+        DBG_STAMP(7);
         if (*flag == 0) return;
         if (active && kpart == 0) {
 #pragma unroll
@@ -407,6 +431,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             }
         }
     }
+    DBG_STAMP(8);
     // ---- epilogue: bias + embedding + residual, coalesced along l ------------------------------------
     if (active && kpart == 0) {
 #pragma unroll
@@ -428,6 +453,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             }
         }
     }
+    if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_STAMP(9); }
+#undef DBG_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -560,6 +587,7 @@ struct surfd_unet {
     float *temb = nullptr, *h1 = nullptr, *emb = nullptr, *emb_table = nullptr; int emb_rows_cap = 0; int emb_rows = 0, emb_B = 0;
     int64_t *t_dev = nullptr; int t_cap = 0;
     float *part = nullptr; size_t part_floats = 0;     // split-K partial tiles
+    long long *dbg = nullptr; int dbg_launch = 0;      // SURFD_CONV_DEBUG=1: per-launch phase stamps
     int *counters = nullptr;
 };
 
@@ -851,6 +879,7 @@ int unet_alloc(surfd_unet *u) {
     HIP_TRY(hipMalloc((void **)&u->part, u->part_floats * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&u->counters, 8192 * sizeof(int)));
     HIP_TRY(hipMemset(u->counters, 0, 8192 * sizeof(int)));
+    if (getenv("SURFD_CONV_DEBUG")) { HIP_TRY(hipMalloc((void **)&u->dbg, 4096 * 16 * sizeof(long long))); HIP_TRY(hipMemset(u->dbg, 0, 4096 * 16 * sizeof(long long))); }
     u->allocated = true;
     return SURFD_OK;
 }
@@ -1114,8 +1143,20 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     if (c.res.buf != -1) { const Resolved r = resolve(c.res, c.ds_out, 0, false); A.res = r.ptr; A.res_bstride = r.bstride; }
     const Resolved o = resolve(c.dst, c.ds_out, 0, true);
     A.out = o.ptr; A.out_bstride = o.bstride;
-    const size_t lds_bytes = ((size_t)bchunk * A.Lsl * cs_max + 3 * 1024 * 2) * sizeof(float);
+    // slab, or (GroupNorm exchange arrays that alias it: 2 floats per row + 2 per (batch, group))
+    bool any_gn = false;
+    for (int s = 0; s < c.nseg; ++s) any_gn |= c.seg[s].gn != 0;
+    A.red_off = bchunk * A.Lsl * cs_max;
+    if (any_gn) A.red_off = std::max(A.red_off, 2 * bchunk * (cs_max - 4) + 2 * bchunk * 32 + 16);
+    A.red_off = (A.red_off + 3) & ~3;
+    const size_t lds_bytes = ((size_t)A.red_off + 3 * 1024 * 2) * sizeof(float);
     dim3 grid(ceil_div(c.Cout, 32), ceil_div(B, bchunk), A.KS);
+    A.dbg = nullptr;
+    if (u->dbg && u->dbg_launch < 4096) {
+        A.dbg = u->dbg + (size_t)(u->dbg_launch++) * 16;
+        long long meta[6] = {c.Cout, c.seg[0].C, A.Lout, grid.x * grid.y * grid.z, A.KS, bchunk};
+        HIP_TRY(hipMemcpyAsync(A.dbg + 10, meta, sizeof(meta), hipMemcpyHostToDevice, st));
+    }
     switch (log2lv) {
         case -1: hipLaunchKernelGGL(conv_kernel<-1>, grid, dim3(256), lds_bytes, st, A); break;
         case 0: hipLaunchKernelGGL(conv_kernel<0>, grid, dim3(256), lds_bytes, st, A); break;
@@ -1229,6 +1270,14 @@ int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, i
 }
 
 }  // namespace surfd
+
+extern "C" int surfd_unet_debug_read(surfd_unet *u, long long *out, int max_launches) {
+    if (!u || !u->dbg) return 0;
+    const int n = std::min(u->dbg_launch, max_launches);
+    if (hipMemcpy(out, u->dbg, (size_t)n * 16 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    u->dbg_launch = 0;
+    return n;
+}
 
 extern "C" int surfd_unet_forward(surfd_unet *u, const float *x, const int64_t *t, const float *ctx, const int64_t *cls,
                                   float *out, int B, int L, surfd_stream s) {
