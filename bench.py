@@ -92,6 +92,9 @@ def cpu_baseline(T, B, n_fwd, n_grad):
     from oracle import decoder as odec
     from oracle import unet as ounet
     from surfd_amd import synth
+    # torch's CPU kernels stop scaling (and oversubscribe) far below the core count of a GPU host:
+    # 32 threads was the fastest setting for this op mix; "cores" reports what was actually used
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     sd = synth.synth_unet_state_dict()
     x = torch.randn(B, 1, 32)
     t = torch.full((B,), 500)

@@ -11,6 +11,7 @@
 // against the oracle to the last bit given the same x0.
 #include "common.h"
 #include "unet_api.h"
+#include <string.h>
 
 namespace surfd {
 
@@ -80,6 +81,56 @@ int surfd_ddim_step(const float *x_t, const float *x0, const float *z, float sqr
                        as_stream(s));
 }
 
+}  // extern "C"
+
+// ---- graph-replayed loop ---------------------------------------------------------------------------
+// The ~115 launches of one iteration are captured ONCE into a hipGraph and replayed T' times: at
+// ~23 us of host time per launch the direct loop was host-bound (2.6 s for 1000 steps).  Everything
+// that changes from iteration to iteration is read on the device through a loop counter: the
+// embedding rows (unet.hip), the coefficient row, the noise row and the trajectory slot.
+namespace surfd {
+
+struct LoopParams {          // device-resident; refreshed per call so the cached graph is pointer-free
+    const float *noise;      // [T'+1, n]
+    float *traj;             // [T', n] or null
+    int T;
+};
+
+// one row per loop iteration k (t index i = T'-1-k): DDPM {c1, c2, logvar, nonzero} / DDIM {sra, srm1, ab, abp, nonzero}
+__global__ void loop_step_kernel(int sampler, int clip, float eta, const float *tab, const LoopParams *lp,
+                                 const int *step_ptr, float *x, const float *x0, long n) {
+    const int k = *step_ptr;
+    const float *row = tab + (long)k * 8;
+    const float *z = lp->noise + (long)(1 + k) * n;
+    float *tr = lp->traj ? lp->traj + (long)k * n : nullptr;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        float xs = x0[e];
+        if (clip) xs = fminf(fmaxf(xs, -1.f), 1.f);
+        float out;
+        if (sampler == 0) {
+            const float mean = __fadd_rn(__fmul_rn(row[0], xs), __fmul_rn(row[1], x[e]));
+            const float sd = expf(__fmul_rn(0.5f, row[2]));
+            out = __fadd_rn(mean, __fmul_rn(__fmul_rn(row[3], sd), z[e]));
+        } else {
+            const float sra = row[0], srm1 = row[1], ab = row[2], abp = row[3];
+            const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(sra, x[e]), xs), srm1);
+            const float sigma = __fmul_rn(__fmul_rn(eta, __fsqrt_rn(__fdiv_rn(__fsub_rn(1.f, abp), __fsub_rn(1.f, ab)))),
+                                          __fsqrt_rn(__fsub_rn(1.f, __fdiv_rn(ab, abp))));
+            const float mean = __fadd_rn(__fmul_rn(xs, __fsqrt_rn(abp)),
+                                         __fmul_rn(__fsqrt_rn(__fsub_rn(__fsub_rn(1.f, abp), __fmul_rn(sigma, sigma))), eps));
+            out = __fadd_rn(mean, __fmul_rn(__fmul_rn(row[4], sigma), z[e]));
+        }
+        x[e] = out;
+        if (tr) tr[e] = out;
+    }
+}
+
+__global__ void loop_advance_kernel(int *step_ptr) { *step_ptr += 1; }
+
+}  // namespace surfd
+
+extern "C" {
+
 int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise, const float *ctx,
                       const int64_t *cls, float *x_out, float *traj, int B, int L, surfd_stream s) {
     if (!u || !cfg || !noise || !x_out || B < 1 || L < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad argument");
@@ -91,36 +142,79 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
         SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: DDIM tables missing");
     hipStream_t st = as_stream(s);
     const long n = (long)B * L;
+    prof_begin(PROF_LOOP, st);
     // every timestep-only quantity of the denoiser for all T' iterations at once: loop
     // iteration k runs original timestep timestep_map[T'-1-k] for every sample
     std::vector<int64_t> t_rows((size_t)T * B);
     for (int k = 0; k < T; ++k)
         for (int b = 0; b < B; ++b) t_rows[(size_t)k * B + b] = cfg->timestep_map[T - 1 - k];
-    prof_begin(PROF_LOOP, st);
     int rc = unet_prepare_embeddings(u, t_rows.data(), T * B, ctx, cls, B, st);
     if (rc) return rc;
-    // ping-pong the state inside the caller's buffers: x lives in x_out, x0 prediction in a
-    // library scratch obtained from the handle (the forward writes straight into it)
-    float *x0 = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&x0, n * sizeof(float), st));
-    HIP_TRY(hipMemcpyAsync(x_out, noise, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    LoopState *ls = unet_loop_state(u);
+    if (!ls->step_ctr) {
+        HIP_TRY(hipMalloc((void **)&ls->step_ctr, sizeof(int)));
+        HIP_TRY(hipMalloc(&ls->params, sizeof(LoopParams)));
+    }
+    if ((size_t)n > ls->cap) {
+        if (ls->x) HIP_TRY(hipFree(ls->x));
+        if (ls->x0) HIP_TRY(hipFree(ls->x0));
+        HIP_TRY(hipMalloc((void **)&ls->x, n * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&ls->x0, n * sizeof(float)));
+        ls->cap = n;
+        ls->key[0] = 0;                       // pointers baked into the cached graph changed
+    }
+    if (T > ls->tab_cap) {
+        if (ls->tab) HIP_TRY(hipFree(ls->tab));
+        HIP_TRY(hipMalloc((void **)&ls->tab, (size_t)T * 8 * sizeof(float)));
+        ls->tab_cap = T;
+        ls->key[0] = 0;
+    }
+    std::vector<float> tab((size_t)T * 8, 0.f);
     for (int k = 0; k < T; ++k) {
         const int i = T - 1 - k;
-        if ((rc = unet_forward_prepared(u, x_out, k * B, x0, B, L, st))) break;
-        const float *z = noise + (size_t)(1 + k) * n;
-        float *dst = traj ? traj + (size_t)k * n : x_out;
-        if (cfg->sampler == 0)
-            rc = launch_ddpm(x_out, x0, z, cfg->coef1[i], cfg->coef2[i], cfg->log_variance[i], i != 0,
-                             cfg->clip_denoised, dst, n, st);
-        else
-            rc = launch_ddim(x_out, x0, z, cfg->sqrt_recip_ab[i], cfg->sqrt_recipm1_ab[i], cfg->ab[i], cfg->ab_prev[i],
-                             cfg->eta, i != 0, cfg->clip_denoised, dst, n, st);
-        if (rc) break;
-        if (traj) HIP_TRY(hipMemcpyAsync(x_out, dst, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        float *row = &tab[(size_t)k * 8];
+        if (cfg->sampler == 0) { row[0] = cfg->coef1[i]; row[1] = cfg->coef2[i]; row[2] = cfg->log_variance[i]; row[3] = i != 0 ? 1.f : 0.f; }
+        else { row[0] = cfg->sqrt_recip_ab[i]; row[1] = cfg->sqrt_recipm1_ab[i]; row[2] = cfg->ab[i]; row[3] = cfg->ab_prev[i]; row[4] = i != 0 ? 1.f : 0.f; }
     }
-    (void)hipFreeAsync(x0, st);
+    LoopParams lp{noise, traj, T};
+    HIP_TRY(hipMemcpyAsync(ls->tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ls->params, &lp, sizeof(lp), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ls->step_ctr, 0, sizeof(int), st));
+    HIP_TRY(hipMemcpyAsync(ls->x, noise, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));        // host staging buffers above go out of scope; also quiesces before capture
+    // ---- (re)capture one iteration if the shape of the step changed ---------------------------
+    float eta_bits_f = cfg->eta;
+    long eta_bits = 0;
+    memcpy(&eta_bits, &eta_bits_f, sizeof(float));
+    const long key[6] = {1, B, L, cfg->sampler, cfg->clip_denoised, eta_bits};
+    if (memcmp(key, ls->key, sizeof(key)) != 0) {
+        if (ls->exec) { (void)hipGraphExecDestroy(ls->exec); ls->exec = nullptr; }
+        if (ls->graph) { (void)hipGraphDestroy(ls->graph); ls->graph = nullptr; }
+        // dry run outside capture: sizes the workspace (allocations are illegal while capturing)
+        if ((rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, st, ls->step_ctr))) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!ls->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&ls->cap_stream, hipStreamNonBlocking));
+        hipStream_t cs = ls->cap_stream;
+        HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, cs, ls->step_ctr);
+        if (!rc) {
+            hipLaunchKernelGGL(loop_step_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n, 256), 64)), dim3(256), 0, cs,
+                               cfg->sampler, cfg->clip_denoised, cfg->eta, (const float *)ls->tab,
+                               (const LoopParams *)ls->params, (const int *)ls->step_ctr, ls->x, (const float *)ls->x0, n);
+            hipLaunchKernelGGL(loop_advance_kernel, dim3(1), dim3(1), 0, cs, ls->step_ctr);
+        }
+        hipGraph_t g = nullptr;
+        hipError_t ce = hipStreamEndCapture(cs, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (ce != hipSuccess) SURFD_FAIL(SURFD_ERR_HIP, "surfd_sample_loop: stream capture failed: %s", hipGetErrorString(ce));
+        ls->graph = g;
+        HIP_TRY(hipGraphInstantiate(&ls->exec, g, nullptr, nullptr, 0));
+        memcpy(ls->key, key, sizeof(key));
+    }
+    for (int k = 0; k < T; ++k) HIP_TRY(hipGraphLaunch(ls->exec, st));
+    HIP_TRY(hipMemcpyAsync(x_out, ls->x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     prof_end(PROF_LOOP, st);
-    return rc;
+    return SURFD_OK;
 }
 
 }  // extern "C"

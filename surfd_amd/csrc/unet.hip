@@ -67,13 +67,26 @@ struct ConvArgs {
     int part_stride;       // floats per partial tile set (column tiles x 1024)
     int *counters;         // [gridDim.y][gridDim.x], zero between launches
     long long *dbg;        // optional: phase timestamps of workgroup (0,0,last slice), 16 slots
+    const int *step_ptr;   // optional: device loop counter; embedding rows advance by emb_step_stride per step
+    long emb_step_stride;
 };
 
 constexpr int CONV_CT_MAX = 4;   // column tiles (32 output positions each) per wave
 constexpr int CONV_VEC_MAX = 16;  // float4 registers a thread may hold while staging (64 floats)
 constexpr int CONV_U = 8;         // weight fragments fetched per software-pipeline stage
 
-__device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
+// SiLU with the hardware exp/rcp (each ~1 ulp): ~6 instructions instead of ~40 for expf + IEEE divide;
+// the operand staging applies it to every element of every GroupNorm'd activation
+__device__ __forceinline__ float silu(float v) { return v * __frcp_rn(1.f + __expf(-v)); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global load (s_waitcnt vmcnt(0)), which would serialise the weight fragments that are deliberately
+// kept in flight across the staging / GroupNorm phases.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // LOG2_LV >= 0: operand rows have Lin = 4 << LOG2_LV positions (4..64), staged one (batch, channel)
 //               row per thread as LV float4 loads issued back to back;
@@ -84,7 +97,7 @@ template <int LOG2_LV, bool PARTIAL = false>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     constexpr bool LIN1 = LOG2_LV < 0;
     constexpr int LV = LIN1 ? 1 : (1 << LOG2_LV);
-    constexpr int RPT = CONV_VEC_MAX / LV;        // rows (or vectors, LIN1) per thread
+    constexpr int RPT = (CONV_VEC_MAX / LV) > 0 ? (CONV_VEC_MAX / LV) : 1;   // rows (or vectors, LIN1) per thread
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
@@ -118,8 +131,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     float *red = lds + A.red_off;   // cross-wave K reduction scratch
     const int kz = blockIdx.z;
     int chunk_id = 0;
+    // phase stamps exist only in -DSURFD_CONV_STAMPS builds: even a never-taken stamp branch makes
+    // the compiler drain every in-flight load (s_waitcnt vmcnt(0)) behind it
+#ifdef SURFD_CONV_STAMPS
     const bool dbg_on = A.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
 #define DBG_STAMP(slot) do { if (dbg_on) A.dbg[(slot)] = (long long)clock64(); } while (0)
+#else
+    constexpr bool dbg_on = false;
+#define DBG_STAMP(slot) do { } while (0)
+#endif
     DBG_STAMP(0);
 
     for (int si = 0; si < A.nseg; ++si) {
@@ -138,15 +158,24 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             const int iters = S.taps * nkg;
             const int ngroups = (iters + CONV_U - 1) / CONV_U;
             const int wk0 = S.kg_off + (c0 >> 3);
-            f32x4 a_cur[CONV_U], a_nxt[CONV_U];
-            if (active && kpart < ngroups) {
+            // three groups of weight fragments (24 KB per wave) are kept in flight: the HBM/MALL
+            // latency (~2 us) is longer than one group of MFMAs (~1 us)
+            f32x4 aA[CONV_U], aB[CONV_U], aC[CONV_U];
+            auto load_group = [&](f32x4 (&dst)[CONV_U], int g) {
+                if (g < ngroups) {
 #pragma unroll
-                for (int u = 0; u < CONV_U; ++u) {
-                    const int it = min(kpart * CONV_U + u, iters - 1);
-                    a_cur[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
+                    for (int u = 0; u < CONV_U; ++u) {
+                        const int it = min(g * CONV_U + u, iters - 1);
+                        dst[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
+                    }
                 }
+            };
+            if (active) {
+                load_group(aA, kpart);
+                load_group(aB, kpart + KP);
+                load_group(aC, kpart + 2 * KP);
             }
-            __syncthreads();   // previous chunk's MFMA reads are done
+            lds_barrier();   // previous chunk's MFMA reads are done
             DBG_STAMP(1);
             if constexpr (LIN1) {
                 // ---- length-1 operand: float4 along channels -------------------------------------
@@ -180,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                         *reinterpret_cast<f32x4 *>(lds + (b * A.Lsl) * cs + 4 * j) = w;
                     }
                 }
-                __syncthreads();
+                lds_barrier();
             } else {
                 // ---- one (batch, channel) row per thread: LV float4 loads in flight per row ------------
                 const int rows = nb * cc;
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                             rowmean[r] = rm; rowm2[r] = m2;
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();
                     // group statistics: equal-size rows combine exactly (Chan et al.):
                     //   mean = avg(row means),  M2 = sum(row M2) + Lin * sum((row mean - mean)^2)
                     for (int q = tid; q < nb * ng; q += 256) {
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                         gstat[2 * q] = gm;
                         gstat[2 * q + 1] = 1.f / sqrtf((m2 + (float)S.Lin * dev) * inv_cnt + 1e-5f);
                     }
-                    __syncthreads();
+                    lds_barrier();
                     float scal[RPT], gmean[RPT];
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                         const int q = (r < rows) ? rb[i] * ng + rc[i] / gs : 0;
                         gmean[i] = gstat[2 * q]; scal[i] = gstat[2 * q + 1];
                     }
-                    __syncthreads();      // exchange arrays are dead: the slab may be written now
+                    lds_barrier();      // exchange arrays are dead: the slab may be written now
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
                         const int r = tid + 256 * i;
@@ -311,21 +340,13 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     const int p = z < pad ? z : Lcov + z;
                     lds[((r / cc) * A.Lsl + p) * cs + (r % cc)] = 0.f;
                 }
-                __syncthreads();
+                lds_barrier();
             }
             DBG_STAMP(4);
             // ---- MFMA over (tap, 8-channel group); weight fragments prefetched one stage ahead ------------
             if (active) {
-                int g = kpart;
-                for (; g < ngroups; g += KP) {
-                    const int gnx = g + KP;
-                    if (gnx < ngroups) {
-#pragma unroll
-                        for (int u = 0; u < CONV_U; ++u) {
-                            const int it = min(gnx * CONV_U + u, iters - 1);
-                            a_nxt[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
-                        }
-                    }
+                auto compute_group = [&](const f32x4 (&a)[CONV_U], int g) {
+                    if (g >= ngroups) return;
                     // operand fragments are fetched one iteration ahead of the MFMAs that consume them
                     f32x4 bq[CONV_CT_MAX], bn[CONV_CT_MAX];
                     {
@@ -351,15 +372,21 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                                 if (ct0 + i * ct_step < nct) {
 #pragma unroll
                                     for (int q = 0; q < 4; ++q)
-                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][q], bq[i][q], acc[i], 0, 0, 0);
+                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], bq[i][q], acc[i], 0, 0, 0);
                                 }
                             }
                         }
 #pragma unroll
                         for (int i = 0; i < CONV_CT_MAX; ++i) bq[i] = bn[i];
                     }
-#pragma unroll
-                    for (int u = 0; u < CONV_U; ++u) a_cur[u] = a_nxt[u];
+                };
+                for (int g = kpart; g < ngroups; g += 3 * KP) {
+                    compute_group(aA, g);
+                    load_group(aA, g + 3 * KP);
+                    compute_group(aB, g + KP);
+                    load_group(aB, g + 4 * KP);
+                    compute_group(aC, g + 2 * KP);
+                    load_group(aC, g + 5 * KP);
                 }
             }
         }
@@ -367,13 +394,13 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     DBG_STAMP(5);
     // ---- cross-wave K reduction (only when spare waves split K) --------------------------------
     if (KP > 1) {
-        __syncthreads();
+        lds_barrier();
         if (active && kpart > 0) {
             float *dst = red + ((size_t)(kpart - 1) * nct + ct0) * 1024;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[0][r];
         }
-        __syncthreads();
+        lds_barrier();
         if (active && kpart == 0) {
             for (int kp = 1; kp < KP; ++kp) {
                 const float *srcp = red + ((size_t)(kp - 1) * nct + ct0) * 1024;
@@ -433,6 +460,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     }
     DBG_STAMP(8);
     // ---- epilogue: bias + embedding + residual, coalesced along l ------------------------------------
+    const float *embp = A.emb;
+    if (embp && A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
     if (active && kpart == 0) {
 #pragma unroll
         for (int i = 0; i < CONV_CT_MAX; ++i) {
@@ -447,7 +476,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                 if (co >= A.Cout) continue;
                 float v = acc[i][r];
                 if (A.bias) v += A.bias[co];
-                if (A.emb) v += A.emb[b * A.emb_bstride + co];
+                if (embp) v += embp[b * A.emb_bstride + co];
                 if (A.res) v += A.res[b * A.res_bstride + (long)co * A.Lout + l];
                 A.out[b * A.out_bstride + (long)co * A.Lout + l] = v;
             }
@@ -588,6 +617,7 @@ struct surfd_unet {
     int64_t *t_dev = nullptr; int t_cap = 0;
     float *part = nullptr; size_t part_floats = 0;     // split-K partial tiles
     long long *dbg = nullptr; int dbg_launch = 0;      // SURFD_CONV_DEBUG=1: per-launch phase stamps
+    surfd::LoopState loop;
     int *counters = nullptr;
 };
 
@@ -932,6 +962,10 @@ void surfd_unet_destroy(surfd_unet *u) {
     if (u->t_dev) (void)hipFree(u->t_dev);
     if (u->part) (void)hipFree(u->part);
     if (u->counters) (void)hipFree(u->counters);
+    if (u->loop.exec) (void)hipGraphExecDestroy(u->loop.exec);
+    if (u->loop.graph) (void)hipGraphDestroy(u->loop.graph);
+    if (u->loop.cap_stream) (void)hipStreamDestroy(u->loop.cap_stream);
+    for (void *p : {(void *)u->loop.step_ctr, (void *)u->loop.x, (void *)u->loop.x0, u->loop.params, (void *)u->loop.tab}) if (p) (void)hipFree(p);
     delete u;
 }
 
@@ -1043,7 +1077,8 @@ struct Resolved { float *ptr; long bstride; };
 
 // Launch one planned convolution.  `B` batch entries, operand length Lseg(ds) = ds ? L/ds : 1.
 int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext_in[2], const long ext_in_bs[2],
-                const int ext_bmod[2], float *ext_out, long ext_out_bs, const float *emb, long emb_bs, hipStream_t st) {
+                const int ext_bmod[2], float *ext_out, long ext_out_bs, const float *emb, long emb_bs, hipStream_t st,
+                const int *step_ptr = nullptr) {
     ConvArgs A;
     memset(&A, 0, sizeof(A));
     A.nseg = c.nseg; A.Cout = c.Cout; A.B = B;
@@ -1098,9 +1133,12 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     if (log2lv == -2) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand length %d (supported: 1, 2, 4, 8, 16, 32, 64)", Lin0);
     const int lin_regs = std::max(Lin0, 4);
     // a thread stages at most CONV_VEC_MAX float4 in registers: nb * cc * Lin <= 256 * 128 floats
-    const long reg_cap = 256L * CONV_VEC_MAX * 4;
+    const long reg_cap = 256L * CONV_VEC_MAX * 4;   // floats a workgroup can hold in registers while staging
     auto fits = [&](int bc, int cc) {
-        return (long)bc * A.Lsl * (cc + 4) <= budget && (long)bc * cc * lin_regs <= reg_cap;
+        const int lv = lin_regs / 4;                                     // float4 per row
+        const long rpt = std::max(1, CONV_VEC_MAX / lv);                  // rows a thread can hold
+        const long rows = linear ? (long)bc * cc / 4 : (long)bc * cc;    // (vectors for Linear layers)
+        return (long)bc * A.Lsl * (cc + 4) <= budget && rows <= 256 * rpt && reg_cap > 0;
     };
     int bchunk = std::min(B, std::max(1, 512 / A.Lout));
     while (bchunk > 1 && !fits(bchunk, need)) --bchunk;
@@ -1139,7 +1177,7 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         A.part = u->part; A.counters = u->counters;
     }
     A.cs_max = cs_max;
-    if (c.emb_off >= 0 && emb) { A.emb = emb + c.emb_off; A.emb_bstride = emb_bs; }
+    if (c.emb_off >= 0 && emb) { A.emb = emb + c.emb_off; A.emb_bstride = emb_bs; A.step_ptr = step_ptr; A.emb_step_stride = (long)B * emb_bs; }
     if (c.res.buf != -1) { const Resolved r = resolve(c.res, c.ds_out, 0, false); A.res = r.ptr; A.res_bstride = r.bstride; }
     const Resolved o = resolve(c.dst, c.ds_out, 0, true);
     A.out = o.ptr; A.out_bstride = o.bstride;
@@ -1240,7 +1278,10 @@ int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows,
     return unet_prepare_embeddings_dev(u, u->t_dev, rows, ctx, cls, B, st);
 }
 
-int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st) {
+LoopState *unet_loop_state(surfd_unet *u) { return &u->loop; }
+
+int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st,
+                          const int *step_ptr) {
     if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
     if (row0 < 0 || row0 + B > u->emb_rows) SURFD_FAIL(SURFD_ERR_STATE, "unet: embedding rows [%d,%d) not prepared", row0, row0 + B);
     int max_ds = 1;
@@ -1253,7 +1294,7 @@ int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, i
         if (op.kind == 0) {
             const float *in[2] = {x, x}; const long bs[2] = {(long)u->cfg.in_channels * L, (long)u->cfg.in_channels * L};
             const int bm[2] = {0, 0};
-            if ((rc = launch_conv(u, op.conv, B, L, in, bs, bm, out, (long)u->cfg.out_channels * L, emb, u->emb_total, st))) return rc;
+            if ((rc = launch_conv(u, op.conv, B, L, in, bs, bm, out, (long)u->cfg.out_channels * L, emb, u->emb_total, st, step_ptr))) return rc;
         } else {
             const AttnPlan &a = op.attn;
             const int T = L / a.ds, heads = u->cfg.num_heads, d = a.C / heads;
