@@ -57,6 +57,7 @@ struct ConvArgs {
     float *out;
     long out_bstride;
     int Cout, Lout, B;
+    int log2Lout;          // Lout is a power of two
     int bchunk;            // batch entries per workgroup
     int Lsl;               // staged positions per batch entry
     int cs_max;            // LDS row stride of the largest chunk (floats)
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     for (int i = 0; i < CONV_CT_MAX; ++i) {
         int m = (ct0 + i * ct_step) * 32 + (lane & 31);
         if (m >= M) m = 0;
-        colb[i] = m / A.Lout;
-        coll[i] = m % A.Lout;
+        colb[i] = m >> A.log2Lout;
+        coll[i] = m & (A.Lout - 1);
     }
     const f32x4 *wbase = reinterpret_cast<const f32x4 *>(A.wp) + (size_t)tile * A.KGtot * 64 + lane;
     float *red = lds + A.red_off;   // cross-wave K reduction scratch
@@ -151,35 +152,42 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
         for (int c0 = 0; c0 < S.Cp; c0 += S.cc) {
             if ((chunk_id++) % A.KS != kz) continue;          // K slices are dealt round-robin by chunk
             const int cc = min(S.cc, S.Cp - c0);
-            const int cs = cc + 4;
-            // first weight fragments of this chunk: requested before the operand is staged so the
-            // HBM/MALL latency overlaps the staging + GroupNorm phase
+            // Linear operands are staged with power-of-two rows (S.cc) even for a shorter last chunk:
+            // the surplus channels are zero-filled and never multiplied (nkg below uses cc)
+            const int cs = (LIN1 ? S.cc : cc) + 4;
+            // Weight fragments of this chunk.  Each wave owns a contiguous range of the (tap, 8-channel
+            // group) iteration space; three groups of CONV_U fragments (24 KB per wave) are requested
+            // before the operand is staged, so the HBM/MALL latency overlaps staging + GroupNorm.
             const int nkg = cc >> 3;
             const int iters = S.taps * nkg;
-            const int ngroups = (iters + CONV_U - 1) / CONV_U;
+            const int log2kp = (KP == 4) ? 2 : (KP == 2 ? 1 : 0);
+            const int per = (iters + KP - 1) >> log2kp;
+            const int it_beg = kpart * per;
+            const int it_end = min(iters, it_beg + per);
+            const int ngroups = (max(it_end - it_beg, 0) + CONV_U - 1) / CONV_U;
             const int wk0 = S.kg_off + (c0 >> 3);
-            // three groups of weight fragments (24 KB per wave) are kept in flight: the HBM/MALL
-            // latency (~2 us) is longer than one group of MFMAs (~1 us)
             f32x4 aA[CONV_U], aB[CONV_U], aC[CONV_U];
             auto load_group = [&](f32x4 (&dst)[CONV_U], int g) {
                 if (g < ngroups) {
 #pragma unroll
                     for (int u = 0; u < CONV_U; ++u) {
-                        const int it = min(g * CONV_U + u, iters - 1);
-                        dst[u] = wbase[(size_t)(wk0 + (it / nkg) * kgs_per_tap + (it % nkg)) * 64];
+                        const int it = min(it_beg + g * CONV_U + u, it_end - 1);
+                        const int tap = (it >= nkg) + (it >= 2 * nkg);
+                        dst[u] = wbase[(size_t)(wk0 + tap * kgs_per_tap + (it - tap * nkg)) * 64];
                     }
                 }
             };
             if (active) {
-                load_group(aA, kpart);
-                load_group(aB, kpart + KP);
-                load_group(aC, kpart + 2 * KP);
+                load_group(aA, 0);
+                load_group(aB, 1);
+                load_group(aC, 2);
             }
             lds_barrier();   // previous chunk's MFMA reads are done
             DBG_STAMP(1);
             if constexpr (LIN1) {
                 // ---- length-1 operand: float4 along channels -------------------------------------
-                const int vpr = cc >> 2;                      // vectors per batch row
+                const int vpr = S.cc >> 2;                    // vectors per batch row (power of two: no divisions)
+                const int lvpr = 31 - __builtin_clz(vpr);
                 const int nvec = nb * vpr;
                 f32x4 v[RPT];
 #pragma unroll
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     const int e = tid + 256 * i;
                     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (e < nvec) {
-                        const int b = e / vpr, j = e % vpr;
+                        const int b = e >> lvpr, j = e & (vpr - 1);
                         int bs = b0 + b;
                         if (S.bmod) bs %= S.bmod;
                         const int cg = c0 + 4 * j;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                 for (int i = 0; i < RPT; ++i) {
                     const int e = tid + 256 * i;
                     if (e < nvec) {
-                        const int b = e / vpr, j = e % vpr;
+                        const int b = e >> lvpr, j = e & (vpr - 1);
                         f32x4 w = v[i];
                         if (S.act)
 #pragma unroll
@@ -211,17 +219,17 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                 }
                 lds_barrier();
             } else {
-                // ---- one (batch, channel) row per thread: LV float4 loads in flight per row ------------
+                // ---- thread <-> channel of the chunk (cc <= 256), register row i <-> batch entry i (nb <= RPT):
+                //      no integer divisions anywhere in the staging path
                 const int rows = nb * cc;
+                const int c = tid;
+                const int cg = c0 + c;
+                const bool cok = c < cc && cg < S.C;
                 f32x4 v[RPT][LV];
-                int rb[RPT], rc[RPT];
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
-                    const int r = tid + 256 * i;
-                    rb[i] = r / cc; rc[i] = r % cc;
-                    const int cg = c0 + rc[i];
-                    const bool ok = r < rows && cg < S.C;
-                    int bs = b0 + rb[i];
+                    const bool ok = cok && i < nb;
+                    int bs = b0 + i;
                     if (S.bmod) bs %= S.bmod;
                     if constexpr (PARTIAL) {
                         const float *src1 = S.x + bs * S.bstride + (long)cg * S.Lin;
@@ -234,27 +242,20 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     }
                 }
                 if (S.gn) {
-                    if (dbg_on) { asm volatile("" :: "v"(v[0][0][0])); DBG_STAMP(2); }
                     // two-pass GroupNorm statistics without leaving the register file; the small
                     // exchange arrays alias the (not yet written) slab.  gamma/beta are requested
                     // now, consumed after the statistics.
-                    float ga[RPT], be[RPT];
-#pragma unroll
-                    for (int i = 0; i < RPT; ++i) {
-                        const int cg = min(c0 + rc[i], S.C - 1);
-                        ga[i] = S.gamma[cg]; be[i] = S.beta[cg];
-                    }
-                    float *rowmean = lds;                 // [rows]
-                    float *rowm2 = lds + rows;            // [rows]
+                    const float ga = S.gamma[min(cg, S.C - 1)], be = S.beta[min(cg, S.C - 1)];
+                    float *rowmean = lds;                 // [nb][cc]
+                    float *rowm2 = lds + rows;            // [nb][cc]
                     float *gstat = lds + 2 * rows;        // [nb * ng][2]
                     const int ng = cc / gs;
+                    const int gq = c / gs;                // this thread's group within the chunk
                     const float inv_len = 1.f / (float)S.Lin;
                     const float inv_cnt = 1.f / (float)(gs * S.Lin);
-                    // per-row mean and centred second moment, two-pass inside the register file
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
-                        const int r = tid + 256 * i;
-                        if (r < rows) {
+                        if (i < nb && c < cc) {
                             float sacc = 0.f;
 #pragma unroll
                             for (int j = 0; j < LV; ++j) sacc += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                                     const float d = v[i][j][q] - rm;
                                     if (!PARTIAL || 4 * j + q < S.Lin) m2 += d * d;
                                 }
-                            rowmean[r] = rm; rowm2[r] = m2;
+                            rowmean[i * cc + c] = rm; rowm2[i * cc + c] = m2;
                         }
                     }
                     lds_barrier();
@@ -287,21 +288,19 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     float scal[RPT], gmean[RPT];
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
-                        const int r = tid + 256 * i;
-                        const int q = (r < rows) ? rb[i] * ng + rc[i] / gs : 0;
+                        const int q = (i < nb && c < cc) ? i * ng + gq : 0;
                         gmean[i] = gstat[2 * q]; scal[i] = gstat[2 * q + 1];
                     }
                     lds_barrier();      // exchange arrays are dead: the slab may be written now
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
-                        const int r = tid + 256 * i;
-                        if (r < rows && c0 + rc[i] < S.C) {
-                            const float gsc = ga[i] * scal[i];
+                        if (i < nb && cok) {
+                            const float gsc = ga * scal[i];
 #pragma unroll
                             for (int j = 0; j < LV; ++j)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    float w = (v[i][j][q] - gmean[i]) * gsc + be[i];
+                                    float w = (v[i][j][q] - gmean[i]) * gsc + be;
                                     if (S.act) w = silu(w);
                                     v[i][j][q] = w;
                                 }
@@ -316,57 +315,55 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                             for (int q = 0; q < 4; ++q) v[i][j][q] = silu(v[i][j][q]);
                 }
                 DBG_STAMP(3);
-                // ---- write the slab, transposed to [b][position][channel] ---------------------------------
+                // ---- write the slab, transposed to [b][position][channel]; zero the halo positions -----------
+                if (c < cc) {
 #pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = tid + 256 * i;
-                    if (r < rows) {
-                        float *dst = lds + (rb[i] * A.Lsl + pad) * cs + rc[i];
+                    for (int i = 0; i < RPT; ++i) {
+                        if (i < nb) {
+                            float *dst = lds + (i * A.Lsl + pad) * cs + c;
 #pragma unroll
-                        for (int j = 0; j < LV; ++j)
+                            for (int j = 0; j < LV; ++j)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int l = 4 * j + q;
-                                if (PARTIAL && l >= S.Lin) continue;
-                                if (S.ups) { dst[(2 * l) * cs] = v[i][j][q]; dst[(2 * l + 1) * cs] = v[i][j][q]; }
-                                else dst[l * cs] = v[i][j][q];
-                            }
+                                for (int q = 0; q < 4; ++q) {
+                                    const int l = 4 * j + q;
+                                    if (PARTIAL && l >= S.Lin) continue;
+                                    if (S.ups) { dst[(2 * l) * cs] = v[i][j][q]; dst[(2 * l + 1) * cs] = v[i][j][q]; }
+                                    else dst[l * cs] = v[i][j][q];
+                                }
+                            float *row0 = lds + (i * A.Lsl) * cs + c;
+                            for (int p = 0; p < pad; ++p) row0[p * cs] = 0.f;
+                            for (int p = pad + Lcov; p < A.Lsl; ++p) row0[p * cs] = 0.f;
+                        }
                     }
-                }
-                // zero halo: positions outside [pad, pad + Lcov)
-                const int nz = A.Lsl - Lcov;
-                for (int e = tid; e < rows * nz; e += 256) {
-                    const int r = e / nz, z = e % nz;
-                    const int p = z < pad ? z : Lcov + z;
-                    lds[((r / cc) * A.Lsl + p) * cs + (r % cc)] = 0.f;
                 }
                 lds_barrier();
             }
             DBG_STAMP(4);
             // ---- MFMA over (tap, 8-channel group); weight fragments prefetched one stage ahead ------------
             if (active) {
+                int lbase[CONV_CT_MAX];       // per-lane LDS offset of each column tile's operand rows
+#pragma unroll
+                for (int i = 0; i < CONV_CT_MAX; ++i) lbase[i] = (colb[i] * A.Lsl + coll[i] * S.stride) * cs + 4 * (lane >> 5);
+                auto operand = [&](int i, int it) -> f32x4 {
+                    const int tap = (it >= nkg) + (it >= 2 * nkg);
+                    return *reinterpret_cast<const f32x4 *>(lds + lbase[i] + tap * cs + (it - tap * nkg) * 8);
+                };
                 auto compute_group = [&](const f32x4 (&a)[CONV_U], int g) {
                     if (g >= ngroups) return;
+                    const int it0 = it_beg + g * CONV_U;
                     // operand fragments are fetched one iteration ahead of the MFMAs that consume them
                     f32x4 bq[CONV_CT_MAX], bn[CONV_CT_MAX];
-                    {
-                        const int it = min(g * CONV_U, iters - 1);
-                        const int tap = it / nkg, kgi = it % nkg;
 #pragma unroll
-                        for (int i = 0; i < CONV_CT_MAX; ++i)
-                            bq[i] = *reinterpret_cast<const f32x4 *>(lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5)));
-                    }
+                    for (int i = 0; i < CONV_CT_MAX; ++i)
+                        if (ct0 + i * ct_step < nct) bq[i] = operand(i, min(it0, it_end - 1));
 #pragma unroll
                     for (int u = 0; u < CONV_U; ++u) {
-                        const int it = g * CONV_U + u;
-                        {
-                            const int itn = min(it + 1, iters - 1);
-                            const int tap = itn / nkg, kgi = itn % nkg;
+                        const int it = it0 + u;
+                        const int itn = min(it + 1, it_end - 1);
 #pragma unroll
-                            for (int i = 0; i < CONV_CT_MAX; ++i)
-                                bn[i] = *reinterpret_cast<const f32x4 *>(lds + ((colb[i] * A.Lsl + coll[i] * S.stride + tap) * cs + kgi * 8 + 4 * (lane >> 5)));
-                        }
-                        if (it < iters) {
+                        for (int i = 0; i < CONV_CT_MAX; ++i)
+                            if (ct0 + i * ct_step < nct) bn[i] = operand(i, itn);
+                        if (it < it_end) {
 #pragma unroll
                             for (int i = 0; i < CONV_CT_MAX; ++i) {
                                 if (ct0 + i * ct_step < nct) {
@@ -380,13 +377,13 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                         for (int i = 0; i < CONV_CT_MAX; ++i) bq[i] = bn[i];
                     }
                 };
-                for (int g = kpart; g < ngroups; g += 3 * KP) {
+                for (int g = 0; g < ngroups; g += 3) {
                     compute_group(aA, g);
-                    load_group(aA, g + 3 * KP);
-                    compute_group(aB, g + KP);
-                    load_group(aB, g + 4 * KP);
-                    compute_group(aC, g + 2 * KP);
-                    load_group(aC, g + 5 * KP);
+                    load_group(aA, g + 3);
+                    compute_group(aB, g + 1);
+                    load_group(aB, g + 4);
+                    compute_group(aC, g + 2);
+                    load_group(aC, g + 5);
                 }
             }
         }
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             if (ct >= nct) continue;
             const int m = ct * 32 + (lane & 31);
             if (m >= M) continue;
-            const int b = b0 + m / A.Lout, l = m % A.Lout;
+            const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = tile * 32 + frag_row(r, lane);
@@ -1083,6 +1080,9 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     memset(&A, 0, sizeof(A));
     A.nseg = c.nseg; A.Cout = c.Cout; A.B = B;
     A.Lout = c.ds_out ? L / c.ds_out : 1;
+    A.log2Lout = 0;
+    while ((1 << A.log2Lout) < A.Lout) ++A.log2Lout;
+    if ((1 << A.log2Lout) != A.Lout) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: output length %d is not a power of two", A.Lout);
     A.wp = u->wpack + c.w_off; A.KGtot = c.KGtot;
     A.bias = u->vecs + c.bias_off;
     auto resolve = [&](const View &v, int ds, int which, bool is_out) -> Resolved {
@@ -1137,8 +1137,8 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     auto fits = [&](int bc, int cc) {
         const int lv = lin_regs / 4;                                     // float4 per row
         const long rpt = std::max(1, CONV_VEC_MAX / lv);                  // rows a thread can hold
-        const long rows = linear ? (long)bc * cc / 4 : (long)bc * cc;    // (vectors for Linear layers)
-        return (long)bc * A.Lsl * (cc + 4) <= budget && rows <= 256 * rpt && reg_cap > 0;
+        if (!linear) return (long)bc * A.Lsl * (cc + 4) <= budget && bc <= rpt && cc <= 256 && reg_cap > 0;   // thread <-> channel, row <-> batch entry
+        return (long)bc * A.Lsl * (cc + 4) <= budget && (long)bc * cc / 4 <= 256 * rpt;                           // vectors for Linear layers
     };
     int bchunk = std::min(B, std::max(1, 512 / A.Lout));
     while (bchunk > 1 && !fits(bchunk, need)) --bchunk;
@@ -1166,6 +1166,7 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         int cc = std::min(ceil_div(Cp, unit) * unit, 4096);
         if (ks_target > 1) cc = std::min<long>(cc, std::max<long>(unit, ceil_div<long>(ceil_div<long>(work_per_slice, sp.taps), unit) * unit));
         while (cc > unit && !fits(bchunk, cc)) cc -= unit;
+        if (linear) { int p2 = 8; while (p2 * 2 <= cc) p2 *= 2; cc = p2; }   // power-of-two vectors per row (shift addressing)
         A.seg[s].cc = cc;
         nchunks += ceil_div(Cp, cc);
         cs_max = std::max(cs_max, cc + 4);
