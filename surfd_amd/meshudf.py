@@ -43,6 +43,8 @@ def sample_udf(udf_func: Callable[[Tensor], Tensor], coords: Tensor, max_batch: 
 
 
 def sample_grads(udf_func: Callable[[Tensor], Tensor], coords: Tensor, max_batch: int) -> Tensor:
+    if hasattr(udf_func, "grads"):              # e.g. parallel.ShardedField: evaluates slices, gathers
+        return udf_func.grads(coords, max_batch)
     native = getattr(udf_func, "_surfd_native", None)
     if native is not None:                      # fused forward + reverse sweep, no autograd graph
         dec, lat, sample = native

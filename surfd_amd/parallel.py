@@ -79,3 +79,44 @@ def sample_sharded(diffusion, model, total: int, latent_len: int, sampler: str =
         counts = [shard_range(total, world, r)[1] for r in range(world)]
         return gather_latents(lat, counts), (first, count)
     return lat, (first, count)
+
+
+class ShardedField:
+    """Grid-shard mode (one shape evaluated by several ranks — SURVEY.md §8e, the north-star's "shard the
+    per-sample grid evaluation"): wraps a per-rank ``udf_func`` so that every call splits its query points
+    evenly by index range over the ranks, evaluates the local slice and all_gathers the values
+    (ncclAllGather over xGMI with backend "nccl"; <= 4 B x n per level).  Every rank then holds the full
+    value vector, derives the same refine mask and issues the same next-level queries, so any grid filler
+    that takes a ``udf_func`` (``surfd_amd.meshudf.GridFiller`` through its callback path, or the CPU
+    oracle in the tests) produces the single-process grid on every rank.  ``grads`` does the same for
+    ``sample_grads`` (12 B x n)."""
+
+    def __init__(self, udf_func, grad_func=None):
+        self.udf_func, self.grad_func = udf_func, grad_func
+
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+        return 1, 0
+
+    def _scatter_gather(self, fn, pts: torch.Tensor, width: int) -> torch.Tensor:
+        import torch.distributed as dist
+        world, rank = self._world()
+        n = pts.shape[0]
+        if world == 1 or n == 0:
+            return fn(pts)
+        first, count = shard_range(n, world, rank)
+        local = fn(pts[first:first + count]) if count else pts.new_zeros((0,) + ((width,) if width else ()))
+        counts = [shard_range(n, world, r)[1] for r in range(world)]
+        return gather_latents(local.contiguous(), counts)
+
+    def __call__(self, pts: torch.Tensor) -> torch.Tensor:
+        return self._scatter_gather(self.udf_func, pts, 0)
+
+    def grads(self, pts: torch.Tensor, max_batch: int = 2 ** 16) -> torch.Tensor:
+        """-normalize(grad udf) for all points, evaluated in slices (autograd or the native sweep)."""
+        from .meshudf import sample_grads
+        fn = self.grad_func or (lambda p: sample_grads(self.udf_func, p, max_batch))
+        return self._scatter_gather(fn, pts, 3)

@@ -49,6 +49,28 @@ def _run(total, toy=False):
     return sample_sharded(diff, OracleModel(), total, L, sampler="ddim", seed=7)
 
 
+def _grid_run(N=64):
+    """Grid-shard mode on the CPU: the oracle grid filler driven by a ShardedField over the analytic field
+    (gradients through torch autograd on each rank's slice)."""
+    from oracle import decoder as odec
+    from oracle import gridfiller as ogrid
+    from surfd_amd.parallel import ShardedField
+    field = ShardedField(ogrid.analytic_field, grad_func=lambda p: odec.sample_grads(ogrid.analytic_field, p, 2 ** 16))
+    calls = []
+
+    def counting(p):
+        calls.append(int(p.shape[0]))
+        return field(p)
+    # the oracle's fill_grid calls sample_grads(udf_func, ...) itself: give it a callable whose autograd
+    # path also goes through the sharded evaluation
+    udf, grads, stats = ogrid.fill_grid(counting, N, 2 ** 30, with_grads=False)
+    gi = (udf < ogrid.gradient_threshold(N)).nonzero()
+    ax = ogrid.axis_coords(N)
+    pts = torch.stack([ax[gi[:, 0]], ax[gi[:, 1]], ax[gi[:, 2]]], 1)
+    g = field.grads(pts)
+    return udf, g, stats
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -56,7 +78,8 @@ def _worker(rank, world, port, out):
     try:
         lat, (first, count) = _run(TOTAL)
         toy, _ = _run(TOTAL, toy=True)
-        out[rank] = (lat.clone(), first, count, toy.clone())
+        gu, gg, gstats = _grid_run()
+        out[rank] = (lat.clone(), first, count, toy.clone(), gu.clone(), gg.clone(), gstats["fwd_per_level"])
     finally:
         dist.destroy_process_group()
 
@@ -65,6 +88,7 @@ def test_sharded_equals_single_process():
     torch.set_num_threads(4)
     single, _ = _run(TOTAL)
     single_toy, _ = _run(TOTAL, toy=True)
+    gu1, gg1, gstats1 = _grid_run()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -75,3 +99,6 @@ def test_sharded_equals_single_process():
         assert out[r][0].shape == (TOTAL, 1, L)
         assert torch.equal(out[r][3], single_toy), "sharded sampling differs from the single-process result"
         torch.testing.assert_close(out[r][0], single, rtol=1e-5, atol=1e-5)
+        # grid-shard mode: every rank ends with the single-process grid, bit for bit
+        assert torch.equal(out[r][4], gu1) and out[r][6] == gstats1["fwd_per_level"]
+        assert torch.equal(out[r][5], gg1)
