@@ -69,6 +69,7 @@ struct ConvArgs {
     int *counters;         // [gridDim.y][gridDim.x], zero between launches
     long long *dbg;        // optional: phase timestamps of workgroup (0,0,last slice), 16 slots
     const int *step_ptr;   // optional: device loop counter; embedding rows advance by emb_step_stride per step
+    int ablate;            // developer aid (SURFD_CONV_ABLATE): 1 skip MFMA, 2 +skip GN/act, 3 +skip operand loads, 4 +skip weight loads
     long emb_step_stride;
 };
 
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     constexpr int LV = LIN1 ? 1 : (1 << LOG2_LV);
     constexpr int RPT = (CONV_VEC_MAX / LV) > 0 ? (CONV_VEC_MAX / LV) : 1;   // rows (or vectors, LIN1) per thread
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (A.ablate == 5) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int b0 = blockIdx.y * A.bchunk;
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
         const int Lcov = S.ups ? 2 * S.Lin : S.Lin;          // slab positions covered by source data
         for (int c0 = 0; c0 < S.Cp; c0 += S.cc) {
             if ((chunk_id++) % A.KS != kz) continue;          // K slices are dealt round-robin by chunk
+            if (A.ablate == 6) continue;
             const int cc = min(S.cc, S.Cp - c0);
             // Linear operands are staged with power-of-two rows (S.cc) even for a shorter last chunk:
             // the surplus channels are zero-filled and never multiplied (nkg below uses cc)
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     }
                 }
             };
-            if (active) {
+            if (active && A.ablate < 4) {
                 load_group(aA, 0);
                 load_group(aB, 1);
                 load_group(aC, 2);
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                 f32x4 v[RPT][LV];
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
-                    const bool ok = cok && i < nb;
+                    const bool ok = cok && i < nb && A.ablate < 3;
                     int bs = b0 + i;
                     if (S.bmod) bs %= S.bmod;
                     if constexpr (PARTIAL) {
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                                 }
                         }
                     }
-                } else if (S.act) {
+                } else if (S.act && A.ablate < 2) {
 #pragma unroll
                     for (int i = 0; i < RPT; ++i)
 #pragma unroll
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             }
             DBG_STAMP(4);
             // ---- MFMA over (tap, 8-channel group); weight fragments prefetched one stage ahead ------------
-            if (active) {
+            if (active && A.ablate < 1) {
                 int lbase[CONV_CT_MAX];       // per-lane LDS offset of each column tile's operand rows
 #pragma unroll
                 for (int i = 0; i < CONV_CT_MAX; ++i) lbase[i] = (colb[i] * A.Lsl + coll[i] * S.stride) * cs + 4 * (lane >> 5);
@@ -465,17 +468,26 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             const int ct = ct0 + i * ct_step;
             if (ct >= nct) continue;
             const int m = ct * 32 + (lane & 31);
-            if (m >= M) continue;
+            const bool mok = m < M;
             const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
+            // all epilogue operands are requested first (one memory round trip), then combined and stored
+            float add[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = tile * 32 + frag_row(r, lane);
-                if (co >= A.Cout) continue;
-                float v = acc[i][r];
-                if (A.bias) v += A.bias[co];
-                if (embp) v += embp[b * A.emb_bstride + co];
-                if (A.res) v += A.res[b * A.res_bstride + (long)co * A.Lout + l];
-                A.out[b * A.out_bstride + (long)co * A.Lout + l] = v;
+                const bool ok = mok && co < A.Cout;
+                float t = 0.f;
+                if (ok) {
+                    if (A.bias) t = A.bias[co];
+                    if (embp) t += embp[b * A.emb_bstride + co];
+                    if (A.res) t += A.res[b * A.res_bstride + (long)co * A.Lout + l];
+                }
+                add[r] = t;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = tile * 32 + frag_row(r, lane);
+                if (mok && co < A.Cout) A.out[b * A.out_bstride + (long)co * A.Lout + l] = acc[i][r] + add[r];
             }
         }
     }
@@ -1156,7 +1168,8 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     for (int s = 0; s < c.nseg; ++s) work += (long)c.seg[s].taps * (ceil_div(c.seg[s].C, 8) * 8);
     // the publish/acquire hand-off costs ~8 us: only worth it when a workgroup would otherwise stream
     // more than ~192 KB of weights on its own
-    if (ntiles * nby < 192 && work * 128 > 192 * 1024) ks_target = std::min(16, ceil_div(256, ntiles * nby));
+    static const int nosplit_env = getenv("SURFD_CONV_NOSPLIT") ? 1 : 0;     // developer aid
+    if (!nosplit_env && ntiles * nby < 192 && work * 128 > 192 * 1024) ks_target = std::min(16, ceil_div(256, ntiles * nby));
     const long work_per_slice = ceil_div<long>(work, ks_target);
     int cs_max = 0, nchunks = 0;
     for (int s = 0; s < c.nseg; ++s) {
@@ -1189,6 +1202,8 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     if (any_gn) A.red_off = std::max(A.red_off, 2 * bchunk * (cs_max - 4) + 2 * bchunk * 32 + 16);
     A.red_off = (A.red_off + 3) & ~3;
     const size_t lds_bytes = ((size_t)A.red_off + 3 * 1024 * 2) * sizeof(float);
+    static const int ablate_env = getenv("SURFD_CONV_ABLATE") ? atoi(getenv("SURFD_CONV_ABLATE")) : 0;
+    A.ablate = ablate_env;
     dim3 grid(ceil_div(c.Cout, 32), ceil_div(B, bchunk), A.KS);
     A.dbg = nullptr;
     if (u->dbg && u->dbg_launch < 4096) {
