@@ -74,7 +74,7 @@ struct ConvArgs {
 };
 
 constexpr int CONV_CT_MAX = 4;   // column tiles (32 output positions each) per wave
-constexpr int CONV_VEC_MAX = 16;  // float4 registers a thread may hold while staging (64 floats)
+constexpr int CONV_VEC_MAX = 8;   // float4 registers a thread may hold while staging (32 floats)
 constexpr int CONV_U = 8;         // weight fragments fetched per software-pipeline stage
 
 // SiLU with the hardware exp/rcp (each ~1 ulp): ~6 instructions instead of ~40 for expf + IEEE divide;
@@ -180,11 +180,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     }
                 }
             };
-            if (active && A.ablate < 4) {
-                load_group(aA, 0);
-                load_group(aB, 1);
-                load_group(aC, 2);
-            }
+            // requested AFTER the operand loads below: vmcnt retires in order, so waiting for the (L2-resident)
+            // operand must not also wait for the (HBM-resident) weights
+            auto prefetch_weights = [&]() {
+                if (active && A.ablate < 4) {
+                    load_group(aA, 0);
+                    load_group(aB, 1);
+                    load_group(aC, 2);
+                }
+            };
             lds_barrier();   // previous chunk's MFMA reads are done
             DBG_STAMP(1);
             if constexpr (LIN1) {
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                             for (int q = 0; q < 4; ++q) if (cg + q < S.C) v[i][q] = S.x[bs * S.bstride + cg + q];
                     }
                 }
+                prefetch_weights();
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
                     const int e = tid + 256 * i;
@@ -244,7 +249,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                         for (int j = 0; j < LV; ++j) v[i][j] = ok ? src[j] : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
-                if (S.gn) {
+                prefetch_weights();
+                if (S.gn && A.ablate < 2) {
                     // two-pass GroupNorm statistics without leaving the register file; the small
                     // exchange arrays alias the (not yet written) slab.  gamma/beta are requested
                     // now, consumed after the statistics.
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     DBG_STAMP(6);
     // ---- cross-workgroup K reduction: every slice publishes its partial tiles; the last arriver
     //      sums them in slice order (deterministic) and runs the epilogue.  Publication follows the
-    //      agent-scope release / acquire recipe (cdna_hip_programming.md §6 G16): plain stores ->
-    //      vmcnt(0) -> barrier -> one-lane release fence -> relaxed ticket; last arriver: acquire.
+    //      agent-scope hand-off recipe R1 (cdna_hip_programming.md §6 G16): write-through (sc1) stores ->
+    //      vmcnt(0) in every storing wave -> barrier -> one-lane relaxed ticket; last arriver: acquire.
     if (A.KS > 1) {
         const size_t slot = ((size_t)blockIdx.y * gridDim.x + tile);
         float *mine = A.part + (((size_t)kz * gridDim.y + blockIdx.y) * gridDim.x + tile) * A.part_stride;
@@ -421,17 +427,23 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
 #pragma unroll
             for (int i = 0; i < CONV_CT_MAX; ++i) {
                 const int ct = ct0 + i * ct_step;
-                if (ct < nct)
+                if (ct < nct) {
+                    // write-through (sc1) 16-byte stores: the partial tile leaves this XCD's L2 as it is
+                    // written, so no buffer_wbl2 release fence is needed before the ticket
+                    // (MI355X_MICROARCH.md "publish-large": 3.0 us vs 8.2 us)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[(ct * 16 + r) * 64 + lane] = acc[i][r];
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 val = {acc[i][4 * r4], acc[i][4 * r4 + 1], acc[i][4 * r4 + 2], acc[i][4 * r4 + 3]};
+                        float *dst = mine + ((size_t)(ct * 4 + r4) * 64 + lane) * 4;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(val) : "memory");
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int *flag = reinterpret_cast<int *>(red + 6 * 1024 - 4);
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (prev == A.KS - 1) ? 1 : 0;
             if (last) {
@@ -453,7 +465,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                 for (int z = 0; z < A.KS; ++z) {
                     const float *src = A.part + (((size_t)z * gridDim.y + blockIdx.y) * gridDim.x + tile) * A.part_stride;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][r] += src[(ct * 16 + r) * 64 + lane];
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4 *>(src + ((size_t)(ct * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[i][4 * r4 + q] += pv[q];
+                    }
                 }
             }
         }
