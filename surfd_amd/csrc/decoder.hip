@@ -218,6 +218,14 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
         f32x16 net[2][4], tmp[2][4];
         unsigned msk[GRAD ? NCBN : 1][4];
         zero_acc(net);
+        // scale/shift of the next conditional-BN layer: requested before the GEMM whose epilogue uses
+        // them, so their L2 latency hides behind the MFMAs instead of opening every epilogue
+        float nsa[4], nsb[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int c = 32 * (4 * wave + nt) + col;
+            nsa[nt] = tab[c]; nsb[nt] = tab[H + c];
+        }
         gemm_2x4<KG_E>(E, ES, wpack + OFF_FCP + (size_t)(4 * wave) * KG_E * 256, net, lane);
         {
             float bias[4];
@@ -238,11 +246,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             {
                 float sa[4], sb[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int c = 32 * (4 * wave + nt) + col;
-                    sa[nt] = tab[(2 * k) * 2 * H + c];
-                    sb[nt] = tab[(2 * k) * 2 * H + H + c];
-                }
+                for (int nt = 0; nt < 4; ++nt) { sa[nt] = nsa[nt]; sb[nt] = nsb[nt]; }
                 if constexpr (GRAD) { msk[2 * k][0] = msk[2 * k][1] = msk[2 * k][2] = msk[2 * k][3] = 0u; }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -257,18 +261,21 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             }
             __syncthreads();
             zero_acc(tmp);
+            float sa1[4], sb1[4], bias0[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int c = 32 * (4 * wave + nt) + col;
+                sa1[nt] = tab[(2 * k + 1) * 2 * H + c];
+                sb1[nt] = tab[(2 * k + 1) * 2 * H + H + c];
+                bias0[nt] = vecs[voff_bfc(k, 0) + c];
+            }
             gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 0) + (size_t)(4 * wave) * KG_H * 256, tmp, lane);
             __syncthreads();
             // X <- relu(a*(tmp + bias0) + b), layer 2k+1
             {
                 float sa[4], sb[4], bias[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int c = 32 * (4 * wave + nt) + col;
-                    sa[nt] = tab[(2 * k + 1) * 2 * H + c];
-                    sb[nt] = tab[(2 * k + 1) * 2 * H + H + c];
-                    bias[nt] = vecs[voff_bfc(k, 0) + c];
-                }
+                for (int nt = 0; nt < 4; ++nt) { sa[nt] = sa1[nt]; sb[nt] = sb1[nt]; bias[nt] = bias0[nt]; }
                 if constexpr (GRAD) { msk[2 * k + 1][0] = msk[2 * k + 1][1] = msk[2 * k + 1][2] = msk[2 * k + 1][3] = 0u; }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -283,11 +290,19 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             }
             __syncthreads();
             // net += fc_1(X) + bias1   (residual accumulates straight into the MFMA C operand)
+            float bias1[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int c = 32 * (4 * wave + nt) + col;
+                bias1[nt] = vecs[voff_bfc(k, 1) + c];
+                nsa[nt] = tab[(2 * k + 2) * 2 * H + c];          // next block's first CBN (or the final one)
+                nsb[nt] = tab[(2 * k + 2) * 2 * H + H + c];
+            }
             gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 1) + (size_t)(4 * wave) * KG_H * 256, net, lane);
             {
                 float bias[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) bias[nt] = vecs[voff_bfc(k, 1) + 32 * (4 * wave + nt) + col];
+                for (int nt = 0; nt < 4; ++nt) bias[nt] = bias1[nt];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -304,8 +319,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int c = 32 * (4 * wave + nt) + col;
-                a10[nt] = tab[(2 * NB) * 2 * H + c];
-                sb[nt] = tab[(2 * NB) * 2 * H + H + c];
+                a10[nt] = nsa[nt];
+                sb[nt] = nsb[nt];
                 wo[nt] = vecs[VOFF_WOUT + c];
             }
             if constexpr (GRAD) { msk[2 * NB][0] = msk[2 * NB][1] = msk[2 * NB][2] = msk[2 * NB][3] = 0u; }
