@@ -102,7 +102,10 @@ typedef struct {
 
 /* Whole reverse loop without returning to the host: noise[T'+1,B,1,L] (row 0 = x_T,
  * row 1+k = z of loop iteration k), ctx/cls as in surfd_unet_forward (constant over the
- * loop), x_out[B,1,L]; traj (nullable) [T',B,1,L] receives x after every iteration. */
+ * loop), x_out[B,1,L]; traj (nullable) [T',B,1,L] receives x after every iteration.
+ * One iteration (~117 kernel nodes) is captured once into a hipGraph and replayed T' times on the
+ * caller's stream.  Host-sync once at entry (schedule tables are uploaded and the stream is quiesced
+ * before capture); the T' replays themselves are asynchronous. */
 int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise,
                       const float *ctx, const int64_t *cls, float *x_out, float *traj,
                       int B, int L, surfd_stream s);

@@ -773,16 +773,16 @@ static PtIO make_io(int mode, const float *src, int64_t n) {
 }
 
 int surfd_decoder_logits_emb(surfd_decoder *d, int sample, const float *emb, int64_t n, float *logits, surfd_stream s) {
+    if (n == 0) return SURFD_OK;          // empty query: nothing to do (pointers may be null)
     if (!emb || !logits || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_logits_emb: bad argument");
-    if (n == 0) return SURFD_OK;
     PtIO io = make_io(PT_EMB, emb, n);
     io.out_logit = logits;
     return decoder_launch(d, sample, io, false, ceil_div<long>(n, TP), as_stream(s));
 }
 
 int surfd_decoder_udf(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf, float *logits, surfd_stream s) {
-    if (!pts || (!udf && !logits) || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf: bad argument");
     if (n == 0) return SURFD_OK;
+    if (!pts || (!udf && !logits) || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf: bad argument");
     PtIO io = make_io(PT_XYZ, pts, n);
     io.out_udf = udf; io.out_logit = logits;
     return decoder_launch(d, sample, io, false, ceil_div<long>(n, TP), as_stream(s));
@@ -790,8 +790,8 @@ int surfd_decoder_udf(surfd_decoder *d, int sample, const float *pts, int64_t n,
 
 int surfd_decoder_udf_grad(surfd_decoder *d, int sample, const float *pts, int64_t n, float *udf, float *ngrad,
                            float *dlogit, surfd_stream s) {
-    if (!pts || (!ngrad && !dlogit) || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf_grad: bad argument");
     if (n == 0) return SURFD_OK;
+    if (!pts || (!ngrad && !dlogit) || n < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_udf_grad: bad argument");
     PtIO io = make_io(PT_XYZ, pts, n);
     io.out_udf = udf; io.out_ngrad = ngrad; io.out_dlogit = dlogit;
     return decoder_launch(d, sample, io, true, ceil_div<long>(n, TP), as_stream(s));

@@ -212,6 +212,16 @@ class SpacedDiffusion:
             return inner
         return None
 
+    @staticmethod
+    def _check_cfg_contract(model, model_kwargs):
+        """The fused loop evaluates the denoiser once per step (the wrapper's two evaluations are
+        bit-identical) but keeps the wrapper's own preconditions."""
+        from .mdm import ClassifierFreeSampleModel
+        if isinstance(model, ClassifierFreeSampleModel):
+            assert model.model.cond_mode in ["text", "action"]
+            y = (model_kwargs or {}).get("y", {})
+            _ = y["scale"].view(-1, 1, 1)          # KeyError / AttributeError exactly where the reference would fail
+
     def _fused_loop(self, mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device,
                     return_trajectory=False):
         B, L = shape[0], shape[-1]
@@ -321,6 +331,7 @@ class SpacedDiffusion:
         mdm = self._can_fuse(model, denoised_fn, cond_fn, skip_timesteps, init_image, randomize_class, dump_steps,
                              const_noise, progress, fused)
         if mdm is not None:
+            self._check_cfg_contract(model, model_kwargs)
             dev = device if device is not None else next(model.parameters()).device
             return self._fused_loop(mdm, tuple(shape), "ddpm", noise, noise_stream, clip_denoised, model_kwargs, 0.0, dev,
                                     return_trajectory)
@@ -344,6 +355,7 @@ class SpacedDiffusion:
         mdm = self._can_fuse(model, denoised_fn, cond_fn, skip_timesteps, init_image, randomize_class, None, False,
                              progress, fused)
         if mdm is not None:
+            self._check_cfg_contract(model, model_kwargs)
             dev = device if device is not None else next(model.parameters()).device
             return self._fused_loop(mdm, tuple(shape), "ddim", noise, noise_stream, clip_denoised, model_kwargs, eta, dev)
         final = None

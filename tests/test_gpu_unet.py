@@ -171,3 +171,60 @@ def test_cfg_wrapper_is_identity():
         assert torch.equal(a, b)
     finally:
         model.cond_mode = "img"
+
+
+def test_fused_loop_conditioned_configs():
+    """Configs C4/C5 shape (L=64, per-sample 512-d context; C4 through the CFG wrapper) and the category
+    mode: the one-call fused loop must agree with the generic per-step Python loop on the same model."""
+    from surfd_amd.mdm import ClassifierFreeSampleModel
+    _, dd, _ = _model("no_cond", "ddim10")
+    model, _, _ = _model("img")
+    B, L = 4, 64
+    noise = synth.synth_noise_batch(10, 100, B, L).cuda()
+    ctx = synth.synth_context(100, B).cuda()
+    kw = {"y": {"context": ctx}}
+    a = dd.ddim_sample_loop(model, (B, 1, L), clip_denoised=False, model_kwargs=kw, noise_stream=noise, fused=True)
+    b = dd.ddim_sample_loop(model, (B, 1, L), clip_denoised=False, model_kwargs=kw, noise_stream=noise, fused=False)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # a different context must change the result (conditioning really reaches the fused path)
+    c = dd.ddim_sample_loop(model, (B, 1, L), clip_denoised=False, model_kwargs={"y": {"context": ctx.flip(0).contiguous()}},
+                            noise_stream=noise, fused=True)
+    assert float((a - c).abs().max()) > 1e-3
+    # C4: text mode + classifier-free wrapper (scale 3.0)
+    model.cond_mode = "text"
+    try:
+        w = ClassifierFreeSampleModel(model)
+        kw4 = {"y": {"context": ctx, "scale": torch.full((B,), 3.0).cuda()}}
+        f = dd.ddim_sample_loop(w, (B, 1, L), clip_denoised=False, model_kwargs=kw4, noise_stream=noise, fused=True)
+        g = dd.ddim_sample_loop(w, (B, 1, L), clip_denoised=False, model_kwargs=kw4, noise_stream=noise, fused=False)
+        np.testing.assert_allclose(f.cpu().numpy(), g.cpu().numpy(), rtol=1e-4, atol=1e-4)
+        assert torch.equal(f, a)                                   # guidance is an exact no-op in the reference
+        with pytest.raises(KeyError):                              # the wrapper needs y['scale'] (cfg_sampler.py:26)
+            dd.ddim_sample_loop(w, (B, 1, L), clip_denoised=False, model_kwargs=kw, noise_stream=noise, fused=True)
+    finally:
+        model.cond_mode = "img"
+    cat_model, _, _ = _model("category")
+    labels = torch.tensor([0, 3, 8, 5]).cuda()
+    noise32 = synth.synth_noise_batch(10, 7, B, 32).cuda()
+    kwc = {"y": {"action_text": labels}}
+    p = dd.p_sample_loop(cat_model, (B, 1, 32), clip_denoised=True, model_kwargs=kwc, noise_stream=noise32, fused=True)
+    q = dd.p_sample_loop(cat_model, (B, 1, 32), clip_denoised=True, model_kwargs=kwc, noise_stream=noise32, fused=False)
+    np.testing.assert_allclose(p.cpu().numpy(), q.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_empty_and_single_inputs():
+    from surfd_amd.cbndec import CbnDecoder, make_udf_func
+    from surfd_amd.spec import DecoderConfig
+    dec = CbnDecoder(63, 32, 512, 5)
+    dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig()), strict=True)
+    dec = dec.cuda().eval()
+    lat = torch.zeros(1, 32).cuda()
+    f = make_udf_func(dec, lat)
+    assert f(torch.zeros(0, 3).cuda()).shape == (0,)
+    one = f(torch.tensor([[0.1, -0.2, 0.3]]).cuda())
+    assert one.shape == (1,) and 0.0 <= float(one) <= 0.1
+    dec.bind_latents(lat)
+    u, g = dec.udf_and_ngrad(torch.zeros(0, 3).cuda(), 0)
+    assert u.shape == (0,) and g.shape == (0, 3)
+    with pytest.raises(RuntimeError, match="not bound"):
+        dec.udf(torch.zeros(4, 3).cuda(), 5)                         # latent index outside what was bound
