@@ -73,7 +73,6 @@ struct ConvArgs {
     long emb_step_stride;
 };
 
-constexpr int CONV_CT_MAX = 4;   // column tiles (32 output positions each) per wave
 constexpr int CONV_VEC_MAX = 8;   // float4 registers a thread may hold while staging (32 floats)
 constexpr int CONV_U = 8;         // weight fragments fetched per software-pipeline stage
 
@@ -95,7 +94,10 @@ __device__ __forceinline__ void lds_barrier() {
 // LOG2_LV < 0 : length-1 operands (the Linear layers of the embedding path), staged as float4
 //               along the channel axis.
 // PARTIAL     : rows shorter than one float4 (Lin = 1 or 2 at the deepest levels of short latents).
-template <int LOG2_LV, bool PARTIAL = false>
+// NTW         : column tiles (32 output positions) a wave may own: 1 for almost every launch of the
+//               denoiser (<= 4 tiles per workgroup), 4 for the wide embedding GEMMs.  Keeping the
+//               common case at 1 quarters the unrolled MFMA/epilogue code the instruction cache sees.
+template <int LOG2_LV, bool PARTIAL = false, int NTW = 4>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     constexpr bool LIN1 = LOG2_LV < 0;
     constexpr int LV = LIN1 ? 1 : (1 << LOG2_LV);
@@ -116,15 +118,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     const int ct_step = (KP == 1) ? 4 : nct;
     const bool active = ct0 < nct;
 
-    f32x16 acc[CONV_CT_MAX];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int i = 0; i < CONV_CT_MAX; ++i)
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    int colb[CONV_CT_MAX], coll[CONV_CT_MAX];
+    int colb[NTW], coll[NTW];
 #pragma unroll
-    for (int i = 0; i < CONV_CT_MAX; ++i) {
+    for (int i = 0; i < NTW; ++i) {
         int m = (ct0 + i * ct_step) * 32 + (lane & 31);
         if (m >= M) m = 0;
         colb[i] = m >> A.log2Lout;
@@ -350,9 +352,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             DBG_STAMP(4);
             // ---- MFMA over (tap, 8-channel group); weight fragments prefetched one stage ahead ------------
             if (active && A.ablate < 1) {
-                int lbase[CONV_CT_MAX];       // per-lane LDS offset of each column tile's operand rows
+                int lbase[NTW];       // per-lane LDS offset of each column tile's operand rows
 #pragma unroll
-                for (int i = 0; i < CONV_CT_MAX; ++i) lbase[i] = (colb[i] * A.Lsl + coll[i] * S.stride) * cs + 4 * (lane >> 5);
+                for (int i = 0; i < NTW; ++i) lbase[i] = (colb[i] * A.Lsl + coll[i] * S.stride) * cs + 4 * (lane >> 5);
                 auto operand = [&](int i, int it) -> f32x4 {
                     const int tap = (it >= nkg) + (it >= 2 * nkg);
                     return *reinterpret_cast<const f32x4 *>(lds + lbase[i] + tap * cs + (it - tap * nkg) * 8);
@@ -361,20 +363,20 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     if (g >= ngroups) return;
                     const int it0 = it_beg + g * CONV_U;
                     // operand fragments are fetched one iteration ahead of the MFMAs that consume them
-                    f32x4 bq[CONV_CT_MAX], bn[CONV_CT_MAX];
+                    f32x4 bq[NTW], bn[NTW];
 #pragma unroll
-                    for (int i = 0; i < CONV_CT_MAX; ++i)
+                    for (int i = 0; i < NTW; ++i)
                         if (ct0 + i * ct_step < nct) bq[i] = operand(i, min(it0, it_end - 1));
 #pragma unroll
                     for (int u = 0; u < CONV_U; ++u) {
                         const int it = it0 + u;
                         const int itn = min(it + 1, it_end - 1);
 #pragma unroll
-                        for (int i = 0; i < CONV_CT_MAX; ++i)
+                        for (int i = 0; i < NTW; ++i)
                             if (ct0 + i * ct_step < nct) bn[i] = operand(i, itn);
                         if (it < it_end) {
 #pragma unroll
-                            for (int i = 0; i < CONV_CT_MAX; ++i) {
+                            for (int i = 0; i < NTW; ++i) {
                                 if (ct0 + i * ct_step < nct) {
 #pragma unroll
                                     for (int q = 0; q < 4; ++q)
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                             }
                         }
 #pragma unroll
-                        for (int i = 0; i < CONV_CT_MAX; ++i) bq[i] = bn[i];
+                        for (int i = 0; i < NTW; ++i) bq[i] = bn[i];
                     }
                 };
                 for (int g = 0; g < ngroups; g += 3) {
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
         float *mine = A.part + (((size_t)kz * gridDim.y + blockIdx.y) * gridDim.x + tile) * A.part_stride;
         if (active && kpart == 0) {
 #pragma unroll
-            for (int i = 0; i < CONV_CT_MAX; ++i) {
+            for (int i = 0; i < NTW; ++i) {
                 const int ct = ct0 + i * ct_step;
                 if (ct < nct) {
                     // write-through (sc1) 16-byte stores: the partial tile leaves this XCD's L2 as it is
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
         if (*flag == 0) return;
         if (active && kpart == 0) {
 #pragma unroll
-            for (int i = 0; i < CONV_CT_MAX; ++i) {
+            for (int i = 0; i < NTW; ++i) {
                 const int ct = ct0 + i * ct_step;
                 if (ct >= nct) continue;
 #pragma unroll
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     if (embp && A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
     if (active && kpart == 0) {
 #pragma unroll
-        for (int i = 0; i < CONV_CT_MAX; ++i) {
+        for (int i = 0; i < NTW; ++i) {
             const int ct = ct0 + i * ct_step;
             if (ct >= nct) continue;
             const int m = ct * 32 + (lane & 31);
@@ -922,13 +924,15 @@ int unet_alloc(surfd_unet *u) {
     HIP_TRY(hipMemset(u->vecs, 0, voff * sizeof(float)));
     if (u->cfg.num_classes > 0) HIP_TRY(hipMalloc((void **)&u->label_table, (size_t)u->cfg.num_classes * u->ted * sizeof(float)));
     const int max_lds = 160 * 1024;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+#define SURFD_SET_LDS(K) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds))
+    SURFD_SET_LDS((conv_kernel<-1, false, 1>)); SURFD_SET_LDS((conv_kernel<-1, false, 4>));
+    SURFD_SET_LDS((conv_kernel<0, false, 1>));  SURFD_SET_LDS((conv_kernel<0, false, 4>));
+    SURFD_SET_LDS((conv_kernel<0, true, 1>));   SURFD_SET_LDS((conv_kernel<0, true, 4>));
+    SURFD_SET_LDS((conv_kernel<1, false, 1>));  SURFD_SET_LDS((conv_kernel<1, false, 4>));
+    SURFD_SET_LDS((conv_kernel<2, false, 1>));  SURFD_SET_LDS((conv_kernel<2, false, 4>));
+    SURFD_SET_LDS((conv_kernel<3, false, 1>));  SURFD_SET_LDS((conv_kernel<3, false, 4>));
+    SURFD_SET_LDS((conv_kernel<4, false, 1>));  SURFD_SET_LDS((conv_kernel<4, false, 4>));
+#undef SURFD_SET_LDS
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     u->part_floats = (size_t)16 << 20;                      // 64 MB of partial tiles
     HIP_TRY(hipMalloc((void **)&u->part, u->part_floats * sizeof(float)));
@@ -1227,15 +1231,19 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         long long meta[6] = {c.Cout, c.seg[0].C, A.Lout, grid.x * grid.y * grid.z, A.KS, bchunk};
         HIP_TRY(hipMemcpyAsync(A.dbg + 10, meta, sizeof(meta), hipMemcpyHostToDevice, st));
     }
+    const bool one = ceil_div(bchunk * A.Lout, 32) <= 4;     // every wave owns at most one column tile
+#define SURFD_LAUNCH(LV, P) do { if (one) hipLaunchKernelGGL((conv_kernel<LV, P, 1>), grid, dim3(256), lds_bytes, st, A); \
+                                 else hipLaunchKernelGGL((conv_kernel<LV, P, 4>), grid, dim3(256), lds_bytes, st, A); } while (0)
     switch (log2lv) {
-        case -1: hipLaunchKernelGGL(conv_kernel<-1>, grid, dim3(256), lds_bytes, st, A); break;
-        case 0: hipLaunchKernelGGL(conv_kernel<0>, grid, dim3(256), lds_bytes, st, A); break;
-        case 1: hipLaunchKernelGGL(conv_kernel<1>, grid, dim3(256), lds_bytes, st, A); break;
-        case 2: hipLaunchKernelGGL(conv_kernel<2>, grid, dim3(256), lds_bytes, st, A); break;
-        case 3: hipLaunchKernelGGL(conv_kernel<3>, grid, dim3(256), lds_bytes, st, A); break;
-        case 5: hipLaunchKernelGGL((conv_kernel<0, true>), grid, dim3(256), lds_bytes, st, A); break;
-        default: hipLaunchKernelGGL(conv_kernel<4>, grid, dim3(256), lds_bytes, st, A); break;
+        case -1: SURFD_LAUNCH(-1, false); break;
+        case 0: SURFD_LAUNCH(0, false); break;
+        case 1: SURFD_LAUNCH(1, false); break;
+        case 2: SURFD_LAUNCH(2, false); break;
+        case 3: SURFD_LAUNCH(3, false); break;
+        case 5: SURFD_LAUNCH(0, true); break;
+        default: SURFD_LAUNCH(4, false); break;
     }
+#undef SURFD_LAUNCH
     LAUNCH_CHECK();
     return SURFD_OK;
 }
