@@ -74,7 +74,7 @@ struct ConvArgs {
 };
 
 constexpr int CONV_VEC_MAX = 8;   // float4 registers a thread may hold while staging (32 floats)
-constexpr int CONV_U = 8;         // weight fragments fetched per software-pipeline stage
+constexpr int CONV_U = 4;         // weight fragments fetched per software-pipeline stage
 
 // SiLU with the hardware exp/rcp (each ~1 ulp): ~6 instructions instead of ~40 for expf + IEEE divide;
 // the operand staging applies it to every element of every GroupNorm'd activation
