@@ -136,6 +136,27 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     float *red = lds + A.red_off;   // cross-wave K reduction scratch
     const int kz = blockIdx.z;
     int chunk_id = 0;
+    // Epilogue operands (bias + per-(step,sample) embedding + residual) of this wave's tile, requested at
+    // kernel start when a wave owns a single tile: their round trip hides behind the whole K loop.
+    const float *embp = A.emb;
+    if (embp && A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
+    float pre_add[16];
+    if constexpr (NTW == 1) {
+        const int m = ct0 * 32 + (lane & 31);
+        const bool mok = active && kpart == 0 && m < M;
+        const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = tile * 32 + frag_row(r, lane);
+            float t = 0.f;
+            if (mok && co < A.Cout) {
+                if (A.bias) t = A.bias[co];
+                if (embp) t += embp[b * A.emb_bstride + co];
+                if (A.res) t += A.res[b * A.res_bstride + (long)co * A.Lout + l];
+            }
+            pre_add[r] = t;
+        }
+    }
     // phase stamps exist only in -DSURFD_CONV_STAMPS builds: even a never-taken stamp branch makes
     // the compiler drain every in-flight load (s_waitcnt vmcnt(0)) behind it
 #ifdef SURFD_CONV_STAMPS
@@ -478,8 +499,6 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
     }
     DBG_STAMP(8);
     // ---- epilogue: bias + embedding + residual, coalesced along l ------------------------------------
-    const float *embp = A.emb;
-    if (embp && A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
     if (active && kpart == 0) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
@@ -492,15 +511,19 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
             float add[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = tile * 32 + frag_row(r, lane);
-                const bool ok = mok && co < A.Cout;
-                float t = 0.f;
-                if (ok) {
-                    if (A.bias) t = A.bias[co];
-                    if (embp) t += embp[b * A.emb_bstride + co];
-                    if (A.res) t += A.res[b * A.res_bstride + (long)co * A.Lout + l];
+                if constexpr (NTW == 1) {
+                    add[r] = pre_add[r];
+                } else {
+                    const int co = tile * 32 + frag_row(r, lane);
+                    const bool ok = mok && co < A.Cout;
+                    float t = 0.f;
+                    if (ok) {
+                        if (A.bias) t = A.bias[co];
+                        if (embp) t += embp[b * A.emb_bstride + co];
+                        if (A.res) t += A.res[b * A.res_bstride + (long)co * A.Lout + l];
+                    }
+                    add[r] = t;
                 }
-                add[r] = t;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
