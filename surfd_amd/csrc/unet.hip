@@ -306,15 +306,23 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                     lds_barrier();
                     // group statistics: equal-size rows combine exactly (Chan et al.):
                     //   mean = avg(row means),  M2 = sum(row M2) + Lin * sum((row mean - mean)^2)
-                    for (int q = tid; q < nb * ng; q += 256) {
-                        const int off = (q / ng) * cc + (q % ng) * gs;
+                    // one team of 8 lanes per (batch entry, group): strided partial sums + 3 shuffle steps
+                    // instead of one thread walking up to 56 dependent LDS reads
+                    for (int q0 = 0; q0 < nb * ng; q0 += 32) {
+                        const int q = q0 + (tid >> 3), lt = tid & 7;
+                        const bool qok = q < nb * ng;
+                        const int off = qok ? (q / ng) * cc + (q % ng) * gs : 0;
                         float sm = 0.f;
-                        for (int j = 0; j < gs; ++j) sm += rowmean[off + j];
+                        if (qok) for (int j = lt; j < gs; j += 8) sm += rowmean[off + j];
+                        sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 1);
                         const float gm = sm / (float)gs;
-                        float m2 = 0.f, dev = 0.f;
-                        for (int j = 0; j < gs; ++j) { m2 += rowm2[off + j]; const float d = rowmean[off + j] - gm; dev += d * d; }
-                        gstat[2 * q] = gm;
-                        gstat[2 * q + 1] = 1.f / sqrtf((m2 + (float)S.Lin * dev) * inv_cnt + 1e-5f);
+                        float m2 = 0.f;
+                        if (qok) for (int j = lt; j < gs; j += 8) { const float d = rowmean[off + j] - gm; m2 += rowm2[off + j] + (float)S.Lin * (d * d); }
+                        m2 += __shfl_xor(m2, 4); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 1);
+                        if (qok && lt == 0) {
+                            gstat[2 * q] = gm;
+                            gstat[2 * q + 1] = 1.f / sqrtf(m2 * inv_cnt + 1e-5f);
+                        }
                     }
                     lds_barrier();
                     float scal[RPT], gmean[RPT];
