@@ -567,12 +567,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const float *qkv, long qkv_bs
         w[t * (T + 1) + s] = a;
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 256) {
-        float mx = -INFINITY;
-        for (int s = 0; s < T; ++s) mx = fmaxf(mx, w[t * (T + 1) + s]);
-        float sum = 0.f;
-        for (int s = 0; s < T; ++s) { const float ex = expf(w[t * (T + 1) + s] - mx); w[t * (T + 1) + s] = ex; sum += ex; }
-        for (int s = 0; s < T; ++s) w[t * (T + 1) + s] /= sum;
+    // softmax over keys: 4 lanes per query row (T <= 64 rows -> all 256 threads busy), shuffle-combined
+    {
+        const int t = tid >> 2, lt = tid & 3;
+        if (t < T) {
+            float *row = w + t * (T + 1);
+            float mx = -INFINITY;
+            for (int s = lt; s < T; s += 4) mx = fmaxf(mx, row[s]);
+            mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+            float sum = 0.f;
+            for (int s = lt; s < T; s += 4) { const float ex = expf(row[s] - mx); row[s] = ex; sum += ex; }
+            sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 1);
+            for (int s = lt; s < T; s += 4) row[s] /= sum;
+        }
     }
     __syncthreads();
     float *dst = out + b * out_bstride + (long)h * d * T;
