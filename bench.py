@@ -33,6 +33,7 @@ import torch  # noqa: E402
 
 FWD_FLOP = 5_308_416          # per forward decoder query
 FP32_MFMA_PEAK_TF = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TF = 2500.0     # MI355X dense fp16/bf16 matrix peak (same guide; not the 2:1-sparsity figure)
 
 
 def parse():
@@ -44,6 +45,8 @@ def parse():
     ap.add_argument("--resolution", type=int, default=512)
     ap.add_argument("--diffusion-steps", type=int, default=1000, help="1000 = full DDPM chain (the metric)")
     ap.add_argument("--latent", type=int, default=32)
+    ap.add_argument("--decoder-precision", choices=["f16x2", "fp32"], default="f16x2",
+                    help="forward decoder kernel arithmetic (include/surfd_hip.h: surfd_decoder_set_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -68,7 +71,7 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-def build_models(latent):
+def build_models(latent, precision):
     from surfd_amd import synth
     from surfd_amd.cbndec import CbnDecoder
     from surfd_amd.mdm import create_model_and_diffusion, load_model_wo_clip
@@ -82,6 +85,7 @@ def build_models(latent):
     dec = CbnDecoder(63, latent, 512, 5)
     dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig(latent_dim=latent)), strict=True)
     dec = dec.cuda().eval()
+    dec.set_precision(precision)
     return model, diffusion, dec
 
 
@@ -131,7 +135,7 @@ def main():
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
     L = Nn.lib()
-    model, diffusion, dec = build_models(a.latent)
+    model, diffusion, dec = build_models(a.latent, a.decoder_precision)
     if a.diffusion_steps != 1000:
         from surfd_amd.diffusion import create_gaussian_diffusion
         diffusion = create_gaussian_diffusion(types.SimpleNamespace(noise_schedule="cosine", sigma_small=True),
@@ -186,22 +190,34 @@ def main():
     fwd_launches, fwd_ms = prof["dec_fwd"]
     grad_launches, grad_ms = prof["dec_grad"]
     fwd_flop_total = n_fwd * B * a.steps * FWD_FLOP            # this rank, timed region
-    achieved = fwd_flop_total / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+    algorithmic = fwd_flop_total / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+    if a.decoder_precision == "f16x2":
+        # every algorithmic multiply-add is issued as three fp16 MFMA products (xh*wh + xh*wl + xl*wh):
+        # price the kernel at what it issues against the fp16 matrix peak
+        kname = "decoder_kernel<false, f16x2> (fused encode + 11-layer CBN MLP + sigmoid; split-fp16 operands, fp32 accumulate)"
+        achieved, peak = 3.0 * algorithmic, F16_MFMA_PEAK_TF
+        dtype = "f32 (decoder matrix products as split fp16x2 on the fp16 MFMA pipe with fp32 accumulation; denoiser fp32 MFMA)"
+    else:
+        kname = "decoder_kernel<false> (fused encode + 11-layer CBN MLP + sigmoid)"
+        achieved, peak = algorithmic, FP32_MFMA_PEAK_TF
+        dtype = "f32"
     out = {
         "metric": "shapes/sec end-to-end (1000-step uncond, 512^3 UDF) at 1/2/4/8 GPU",
         "value": shapes / elapsed, "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded random-init weights of the reference architectures, seeded noise)",
+        "dtype": dtype, "data": "synthetic (seeded random-init weights of the reference architectures, seeded noise)",
         "config": {"workload": f"unconditional, {T}-step {'DDPM' if a.diffusion_steps == 1000 else 'DDIM'}, L={a.latent}, "
                                f"{N}^3 coarse-to-fine UDF grid + gradients (end point E1: grids resident in HBM), "
                                f"{B} shapes/GPU (BASELINE configs[2] per-GPU shard)",
                    "shapes_per_gpu": B, "resolution": N, "diffusion_steps": T,
                    "decoder_fwd_queries_per_shape": n_fwd, "decoder_grad_queries_per_shape": n_grad,
+                   "decoder_precision": a.decoder_precision,
                    "parallelism": f"shape-parallel x{world}, no data-path collective"},
-        "roofline": {"kernel": "decoder_kernel<false> (fused encode + 11-layer CBN MLP + sigmoid)", "bound": "mfma",
-                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TF,
+        "roofline": {"kernel": kname, "bound": "mfma",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None, "launches": fwd_launches, "avg_launch_ms": fwd_ms / max(fwd_launches, 1),
-                     "flop_per_point": FWD_FLOP},
+                     "flop_per_point": FWD_FLOP, "algorithmic_tflops": algorithmic,
+                     "mfma_flop_per_point": (3 if a.decoder_precision == "f16x2" else 1) * FWD_FLOP},
         "breakdown_ms_per_step": {"reverse_loop": prof["loop"][1] / a.steps, "decoder_fwd": fwd_ms / a.steps,
                                   "decoder_fwd_bwd": grad_ms / a.steps,
                                   "decoder_fwd_bwd_tflops": (n_grad * B * a.steps * 2 * FWD_FLOP) / (grad_ms * 1e-3) / 1e12 if grad_ms > 0 else 0.0},

@@ -132,6 +132,15 @@ int surfd_decoder_param_info(const surfd_decoder *d, int i, const char **key, in
 int surfd_decoder_set_param(surfd_decoder *d, const char *key, const void *dev_ptr,
                             const int64_t *shape, int ndim, surfd_stream s);
 int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s);
+/* Arithmetic of the FORWARD decoder kernel (udf / logits / grid fill):
+ * 1 = "f16x2" (default): every fp32 operand is split into two fp16 terms (weights pre-scaled by one power
+ *     of two), the three significant products are accumulated in fp32 on the fp16 matrix pipe.  Error
+ *     against an fp64 evaluation is the same size as the plain fp32 kernel's (tests/test_gpu_decoder_grid.py);
+ *     activations saturate at 65504.  2.85x the throughput of mode 0 on MI355X.
+ * 0 = "fp32": v_mfma_f32_32x32x2_f32, bitwise an fmaf chain, no range limit.
+ * The gradient kernel (surfd_decoder_udf_grad) always runs in fp32.  The initial mode can also be set with
+ * SURFD_DECODER_PRECISION=fp32|f16x2. */
+int surfd_decoder_set_precision(surfd_decoder *d, int mode);
 /* lat[S,D]: computes the per-sample conditional-BN scale/shift tables [S,11,2,H]
  * (the 22 per-point Conv1d(D->H) of cbndec.py:74-79 collapse to this when one latent is
  * broadcast to all points, cbndec.py:131-132). */

@@ -169,6 +169,12 @@ class CbnDecoder(nn.Module):
             self._latents_key = None
         return L, self._handle
 
+    def set_precision(self, mode: str) -> None:
+        """Forward-kernel arithmetic: 'f16x2' (default: split-fp16 on the fp16 matrix pipe, fp32-class accuracy,
+        see csrc/decoder.hip) or 'fp32' (exact fp32 MFMA)."""
+        L, h = self._native()
+        N.check(L.surfd_decoder_set_precision(h, {"fp32": 0, "f16x2": 1}[mode]))
+
     def bind_latents(self, latents: Tensor) -> None:
         """latents [S, D]: precompute the per-sample conditional-BN tables once."""
         L, h = self._native()

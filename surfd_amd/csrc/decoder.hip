@@ -23,6 +23,7 @@
 #include "common.h"
 #include "points.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace surfd {
 
@@ -51,8 +52,35 @@ constexpr int VOFF_WOUT = H * (1 + 2 * NB);
 constexpr int VOFF_BOUT = H * (2 + 2 * NB);
 constexpr int VEC_FLOATS = VOFF_BOUT + 4;
 
+// ---- optional "f16x2" forward path (surfd_decoder_set_precision / SURFD_DECODER_PRECISION=f16x2) -----
+// Every fp32 operand is split into two fp16 terms, x = xh + xl with |x - xh - xl| <= 2^-22 |x|, and the
+// three products xh*wh + xh*wl + xl*wh are accumulated in fp32 on the fp16 matrix pipe
+// (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate): 16/3 = 5.3x the fp32 matrix rate at fp32-class
+// accuracy (measured error vs an fp64 evaluation is the same size as the fp32 kernel's own).
+//  * weights are multiplied by one power of two SC (max |W|*SC in [256, 512)) before the split so that
+//    the low terms stay in fp16's normal range; SC is folded back exactly in the epilogues;
+//  * activations live in LDS already split (the producing epilogue splits each value once): row p of
+//    X is [256 words of high halves][256 words of low halves][4 pad], word w = two consecutive k-slots;
+//    k-slot order is chosen so that the epilogue's natural register pairs are the two halves of a word:
+//        slot s -> channel 128*(s>>7) + 64*((s>>6)&1) + 32*(s&1) + ((s>>1)&31)
+//  * activations saturate at 65504 (fp16 max) in this mode; the fp32 path has no such limit.
+// Weight planes, fragment-major for the 32x32x16 MFMA:
+//   whf[(((tile*KS + ks)*2 + plane)*64 + lane)*8 + e] = plane(SC * W[tile*32 + (lane&31)][chan(ks*16 + 8*(lane>>5) + e)])
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int KS_H = H / 16;                  // k16 steps of a 512-deep contraction
+constexpr int KS_E = 4;                       // k16 steps of the 64-deep first layer
+constexpr size_t HF_FCP = (size_t)16 * KS_E * 2 * 64 * 8;     // fp16 elements
+constexpr size_t HF_HH = (size_t)16 * KS_H * 2 * 64 * 8;
+__host__ __device__ constexpr size_t hf_off_fc(int k, int which) { return HF_FCP + (size_t)(2 * k + which) * HF_HH; }
+constexpr size_t WHF_ELEMS = HF_FCP + (size_t)2 * NB * HF_HH;
+constexpr int VOFF_SC = VOFF_BOUT + 1;        // SC, 1/SC (floats) and max|W| bits, after b_out
+__host__ __device__ constexpr int slot_channel(int s) { return 128 * (s >> 7) + 64 * ((s >> 6) & 1) + 32 * (s & 1) + ((s >> 1) & 31); }
+
 struct DecParams {
     const float *wpack;   // WPACK_FLOATS
+    const _Float16 *whf;  // WHF_ELEMS (f16x2 forward path only)
     const float *vecs;    // VEC_FLOATS: biases, w_out, b_out
     const float *tab;     // this sample's [NCBN][2][H] scale/shift
     int input_dim;
@@ -110,6 +138,69 @@ __device__ __forceinline__ void gemm_2x4(const float *A, int astride, const gflo
     }
 }
 
+// two fp32 values -> (high halves, low halves), each a packed pair
+__device__ __forceinline__ void split2(const f32x2 u, unsigned &hi, unsigned &lo) {
+    const f16x2 h = __builtin_convertvector(u, f16x2);
+    const f32x2 r = u - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+typedef f16x8 __attribute__((address_space(1))) gf16x8;
+
+__device__ __forceinline__ void mfma_step_f16x2(const f16x8 (&a)[2][2], const f16x8 (&b)[4][2], f32x16 (&acc)[2][4]) {
+    // term-major: the 8 accumulators are independent, so consecutive MFMAs never wait on each other;
+    // small terms first
+    constexpr int TA[3] = {1, 0, 0};     // activation plane
+    constexpr int TB[3] = {0, 1, 0};     // weight plane
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][TA[t]], b[nt][TB[t]], acc[mt][nt], 0, 0, 0);
+}
+
+// acc[mt][nt] += A[64 x 16*KS] (split fp16 planes in LDS) * W (two fp16 planes, 4 channel tiles of this wave).
+// One k-step is 24 MFMAs = 768 matrix-pipe cycles; the 8 weight fragments of k-step ks+D-1 and the 4
+// activation fragments of ks+1 are requested before the MFMAs of ks are issued (rotating register
+// stages, no copies), so D-1 k-steps of MFMA time cover the L2 latency.
+template <int KS, int D>
+__device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *Whf, f32x16 (&acc)[2][4], int lane) {
+    static_assert(KS % D == 0 && D % 2 == 0, "k-step count must be a multiple of the (even) pipeline depth");
+    const float *a0 = A + (lane & 31) * XS + 4 * (lane >> 5);
+    const float *a1 = a0 + 32 * XS;
+    const gf16x8 *w = reinterpret_cast<const gf16x8 *>((const __attribute__((address_space(1))) _Float16 *)Whf) + lane;
+    f16x8 b[D][4][2], x[2][2][2];
+    auto load_w = [&](f16x8 (&dst)[4][2], int ks) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) dst[nt][q] = w[(size_t)((nt * KS + ks) * 2 + q) * 64];
+    };
+    auto load_x = [&](f16x8 (&dst)[2][2], int ks) {
+        dst[0][0] = *reinterpret_cast<const f16x8 *>(a0 + ks * 8); dst[0][1] = *reinterpret_cast<const f16x8 *>(a0 + 256 + ks * 8);
+        dst[1][0] = *reinterpret_cast<const f16x8 *>(a1 + ks * 8); dst[1][1] = *reinterpret_cast<const f16x8 *>(a1 + 256 + ks * 8);
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load_w(b[d], d);
+    load_x(x[0], 0);
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KS; ks0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int ks = ks0 + j;
+            load_w(b[(j + D - 1) % D], ks + D - 1 < KS ? ks + D - 1 : KS - 1);     // tail: harmless re-load
+            load_x(x[(j + 1) & 1], ks + 1 < KS ? ks + 1 : KS - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step_f16x2(x[j & 1], b[j], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // one 32x32 tile: rows = points [32*mt, +32), cols = packed tile `Wp_tile`
 template <int KG>
 __device__ __forceinline__ void gemm_1x1(const float *A, int astride, int mt, const gfloat *Wp_tile, f32x16 &acc, int lane) {
@@ -137,8 +228,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][4]) {
 __device__ __forceinline__ constexpr int mword(int mt, int nt) { return (mt * 4 + nt) >> 1; }
 __device__ __forceinline__ constexpr int mbit(int mt, int nt, int r) { return ((mt * 4 + nt) & 1) * 16 + r; }
 
-template <bool GRAD>
+template <bool GRAD, bool F16X2 = false>
 __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
+    static_assert(!(GRAD && F16X2), "the reverse sweep is fp32 only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X = lds;                      // [TP][XS]
     float *E = lds;                      // [TP][ES] first-layer input, aliases X (dead before X is written)
@@ -156,13 +248,43 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     float *const xb0 = X + (4 * (lane >> 5)) * XS + 128 * wave + col;
     float *const xb1 = xb0 + 32 * XS;
 #define XAT(mt, nt, r) ((mt) ? xb1 : xb0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (nt)]
+    // f16x2 mode: word (wave, q, col) of plane `pl` in the same rows (see the layout comment at the top)
+    typedef unsigned __attribute__((address_space(3))) lds_u32;
+    lds_u32 *xw0 = (lds_u32 *)(reinterpret_cast<unsigned *>(X) + (4 * (lane >> 5)) * XS + 64 * wave + col);
+    lds_u32 *xw1 = xw0 + 32 * XS;
+#define XW(mt, q, r, pl) ((mt) ? xw1 : xw0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (q) + 256 * (pl)]
+    // X <- split(relu(a*(v + b0) + b)) for this wave's accumulator footprint
+    auto store_split = [&](auto has_bias, const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4], const float (&b0)[4]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x2 a2 = {sa[2 * q], sa[2 * q + 1]}, b2 = {sb[2 * q], sb[2 * q + 1]}, c2 = {b0[2 * q], b0[2 * q + 1]};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 n2 = {v[mt][2 * q][r], v[mt][2 * q + 1][r]};
+                    f32x2 u;
+                    if constexpr (decltype(has_bias)::value) u = a2 * (n2 + c2) + b2;
+                    else u = a2 * n2 + b2;
+                    u.x = __builtin_amdgcn_fmed3f(u.x, 0.f, 65504.f);
+                    u.y = __builtin_amdgcn_fmed3f(u.y, 0.f, 65504.f);
+                    unsigned hi, lo;
+                    split2(u, hi, lo);
+                    XW(mt, q, r, 0) = hi;
+                    XW(mt, q, r, 1) = lo;
+                }
+        }
+    };
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long e0 = tile * TP;
         // re-materialise the arena bases per tile: keeps the compiler from hoisting ~100 derived
         // 64-bit layer addresses out of the tile loop and spilling them to scratch
         const float *wpack_ = P.wpack, *vecs_ = P.vecs, *tab_ = P.tab;
+        const _Float16 *whf = P.whf;
+        int cb = 128 * wave + col;          // first of this lane's four channels (+32 per tile)
         asm volatile("" : "+s"(wpack_), "+s"(vecs_), "+s"(tab_));
+        if constexpr (F16X2) asm volatile("" : "+s"(whf), "+v"(cb), "+v"(xw0), "+v"(xw1));
         // (the asm erases the address space: restore "global" so loads stay global_load, not flat)
         const gfloat *wpack = (const gfloat *)wpack_, *vecs = (const gfloat *)vecs_, *tab = (const gfloat *)tab_;
         __syncthreads();   // previous tile's readers of PT/LOG/E2/DV are done
@@ -187,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
         }
         __syncthreads();
         // ---- 2. positional encoding into E[p][0..63] ---------------------------------------
-        {
+        if constexpr (!F16X2) {
             const int p = tid >> 2, part = tid & 3;
             if (io.mode == PT_EMB) {
                 const long e = e0 + p;
@@ -212,6 +334,30 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                     E[p * ES + j] = v;
                 }
             }
+        } else {
+            // split planes in X's row layout (identity k-slot order for the first layer)
+            const int p = tid >> 2, part = tid & 3;
+            const long e = e0 + p;
+            const float c3[3] = {PT[p * 4 + 0], PT[p * 4 + 1], PT[p * 4 + 2]};
+            auto feature = [&](int j) -> float {
+                if (io.mode == PT_EMB) return (e < npts && j < io.emb_dim) ? io.xyz[e * io.emb_dim + j] : 0.f;
+                if (j < 3) return c3[j];
+                if (j == 63) return 0.f;
+                const int f = (j - 3) / 6, r = (j - 3) % 6;
+                const float a = c3[r % 3] * (float)(1 << f);      // exact: power-of-two scale
+                return (r < 3) ? sinf(a) : cosf(a);
+            };
+            unsigned *row = reinterpret_cast<unsigned *>(X) + p * XS + part * 8;
+#pragma unroll 2
+            for (int i = 0; i < 8; ++i) {
+                f32x2 u = {feature(part * 16 + 2 * i), feature(part * 16 + 2 * i + 1)};
+                u.x = __builtin_amdgcn_fmed3f(u.x, -65504.f, 65504.f);
+                u.y = __builtin_amdgcn_fmed3f(u.y, -65504.f, 65504.f);
+                unsigned hi, lo;
+                split2(u, hi, lo);
+                row[i] = hi;
+                row[256 + i] = lo;
+            }
         }
         __syncthreads();
         // ---- 3. fc_p -----------------------------------------------------------------------
@@ -221,16 +367,21 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
         // scale/shift of the next conditional-BN layer: requested before the GEMM whose epilogue uses
         // them, so their L2 latency hides behind the MFMAs instead of opening every epilogue
         float nsa[4], nsb[4];
+        // f16x2: accumulators carry SC * value; SC (a power of two) is folded back exactly into the
+        // scale of the next conditional BN and into the biases
+        const float wsc = F16X2 ? vecs[VOFF_SC] : 1.f, winv = F16X2 ? vecs[VOFF_SC + 1] : 1.f;
+        auto scl = [](float v, float f) { if constexpr (F16X2) return v * f; else return v; };
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int c = 32 * (4 * wave + nt) + col;
-            nsa[nt] = tab[c]; nsb[nt] = tab[H + c];
+            const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
+            nsa[nt] = scl(tab[c], winv); nsb[nt] = tab[H + c];
         }
-        gemm_2x4<KG_E>(E, ES, wpack + OFF_FCP + (size_t)(4 * wave) * KG_E * 256, net, lane);
+        if constexpr (F16X2) gemm_2x4_f16x2<KS_E, 4>(X, whf + (size_t)(4 * wave) * KS_E * 2 * 512, net, lane);
+        else gemm_2x4<KG_E>(E, ES, wpack + OFF_FCP + (size_t)(4 * wave) * KG_E * 256, net, lane);
         {
             float bias[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bias[nt] = vecs[VOFF_BFCP + 32 * (4 * wave + nt) + col];
+            for (int nt = 0; nt < 4; ++nt) bias[nt] = scl(vecs[VOFF_BFCP + (F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col)], wsc);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -248,6 +399,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) { sa[nt] = nsa[nt]; sb[nt] = nsb[nt]; }
                 if constexpr (GRAD) { msk[2 * k][0] = msk[2 * k][1] = msk[2 * k][2] = msk[2 * k][3] = 0u; }
+                if constexpr (F16X2) {
+                    store_split(std::false_type{}, net, sa, sb, sb);
+                } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -258,18 +412,20 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                             if constexpr (GRAD) if (u > 0.f) msk[2 * k][mword(mt, nt)] |= 1u << mbit(mt, nt, r);
                             XAT(mt, nt, r) = fmaxf(u, 0.f);
                         }
+                }
             }
             __syncthreads();
             zero_acc(tmp);
             float sa1[4], sb1[4], bias0[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int c = 32 * (4 * wave + nt) + col;
-                sa1[nt] = tab[(2 * k + 1) * 2 * H + c];
+                const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
+                sa1[nt] = scl(tab[(2 * k + 1) * 2 * H + c], winv);
                 sb1[nt] = tab[(2 * k + 1) * 2 * H + H + c];
-                bias0[nt] = vecs[voff_bfc(k, 0) + c];
+                bias0[nt] = scl(vecs[voff_bfc(k, 0) + c], wsc);
             }
-            gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 0) + (size_t)(4 * wave) * KG_H * 256, tmp, lane);
+            if constexpr (F16X2) gemm_2x4_f16x2<KS_H, 4>(X, whf + hf_off_fc(k, 0) + (size_t)(4 * wave) * KS_H * 2 * 512, tmp, lane);
+            else gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 0) + (size_t)(4 * wave) * KG_H * 256, tmp, lane);
             __syncthreads();
             // X <- relu(a*(tmp + bias0) + b), layer 2k+1
             {
@@ -277,6 +433,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) { sa[nt] = sa1[nt]; sb[nt] = sb1[nt]; bias[nt] = bias0[nt]; }
                 if constexpr (GRAD) { msk[2 * k + 1][0] = msk[2 * k + 1][1] = msk[2 * k + 1][2] = msk[2 * k + 1][3] = 0u; }
+                if constexpr (F16X2) {
+                    store_split(std::true_type{}, tmp, sa, sb, bias);
+                } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -287,18 +446,20 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                             if constexpr (GRAD) if (u > 0.f) msk[2 * k + 1][mword(mt, nt)] |= 1u << mbit(mt, nt, r);
                             XAT(mt, nt, r) = fmaxf(u, 0.f);
                         }
+                }
             }
             __syncthreads();
             // net += fc_1(X) + bias1   (residual accumulates straight into the MFMA C operand)
             float bias1[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int c = 32 * (4 * wave + nt) + col;
-                bias1[nt] = vecs[voff_bfc(k, 1) + c];
-                nsa[nt] = tab[(2 * k + 2) * 2 * H + c];          // next block's first CBN (or the final one)
+                const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
+                bias1[nt] = scl(vecs[voff_bfc(k, 1) + c], wsc);
+                nsa[nt] = scl(tab[(2 * k + 2) * 2 * H + c], winv);   // next block's first CBN (or the final one)
                 nsb[nt] = tab[(2 * k + 2) * 2 * H + H + c];
             }
-            gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 1) + (size_t)(4 * wave) * KG_H * 256, net, lane);
+            if constexpr (F16X2) gemm_2x4_f16x2<KS_H, 4>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave) * KS_H * 2 * 512, net, lane);
+            else gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 1) + (size_t)(4 * wave) * KG_H * 256, net, lane);
             {
                 float bias[4];
 #pragma unroll
@@ -318,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             float sb[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int c = 32 * (4 * wave + nt) + col;
+                const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
                 a10[nt] = nsa[nt];
                 sb[nt] = nsb[nt];
                 wo[nt] = vecs[VOFF_WOUT + c];
@@ -489,11 +650,50 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 }
 
 #undef XAT
+#undef XW
 constexpr size_t DEC_LDS_BYTES = (size_t)(TP * XS + TP * 4 + TP + TP * ES + TP * 4) * sizeof(float);
 
 // ---------------------------------------------------------------------------------------------
 // per-sample conditional-BN tables
 // ---------------------------------------------------------------------------------------------
+// max |w| over a float range, as the bit pattern of a non-negative float (monotone as unsigned)
+__global__ void absmax_kernel(const float *src, size_t n, unsigned *out) {
+    unsigned m = 0u;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(src[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// SC = 2^(8 - floor(log2 max|W|)): max |W| * SC in [256, 512); sc[0] = SC, sc[1] = 1/SC
+__global__ void weight_scale_kernel(const unsigned *maxbits, float *sc) {
+    const unsigned b = *maxbits;
+    int e = (int)(b >> 23) - 127;
+    if (b == 0u || e > 100 || e < -100) e = 8;         // degenerate weights: SC = 1
+    sc[0] = __uint_as_float((unsigned)(127 + 8 - e) << 23);
+    sc[1] = __uint_as_float((unsigned)(127 - 8 + e) << 23);
+}
+
+// fragment-major fp32 pack (PackDesc layout, KG k-groups per tile) -> two fragment-major fp16 planes of SC*W
+// (layout comment at the top); `permute` selects the hidden-layer k-slot order
+__global__ void pack_f16x2_kernel(const float *wp, int KG, int KS, int permute, const float *sc, _Float16 *dst) {
+    const float scale = sc[0];
+    const long total = (long)16 * KS * 64 * 8;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int el = e & 7, lane = (e >> 3) & 63;
+        const long tk = e >> 9;
+        const int ks = tk % KS, tile = tk / KS;
+        const int slot = ks * 16 + 8 * (lane >> 5) + el;
+        const int k = permute ? slot_channel(slot) : slot;
+        const float x = wp[((size_t)(tile * KG + (k >> 3)) * 64 + (lane & 31) + 32 * ((k >> 2) & 1)) * 4 + (k & 3)] * scale;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const size_t base = ((size_t)(tile * KS + ks) * 2) * 512 + (size_t)lane * 8 + el;
+        dst[base] = h; dst[base + 512] = l;
+    }
+}
+
 struct CbnParams {
     const float *gw[NCBN], *gb[NCBN], *bw[NCBN], *bb[NCBN], *mean[NCBN], *var[NCBN];
 };
@@ -536,6 +736,8 @@ struct surfd_decoder {
     bool allocated = false, finalized = false;
     // private device copies
     float *wpack = nullptr, *vecs = nullptr;
+    _Float16 *whf = nullptr;          // f16x2 planes of the forward matrices (built by finalize)
+    int precision = 1;                // forward kernel: 1 = f16x2 (default), 0 = exact fp32 MFMA
     float *gw[NCBN] = {}, *gb[NCBN] = {}, *bw[NCBN] = {}, *bb[NCBN] = {}, *mean[NCBN] = {}, *var[NCBN] = {};
     float *tab = nullptr;
     int S = 0, tab_cap = 0;
@@ -570,6 +772,9 @@ static int dec_alloc(surfd_decoder *d) {
     int rc;
     if ((rc = A(&d->wpack, WPACK_FLOATS))) return rc;
     if ((rc = A(&d->vecs, VEC_FLOATS))) return rc;
+    HIP_TRY(hipMalloc((void **)&d->whf, WHF_ELEMS * sizeof(_Float16)));
+    d->allocs.push_back(d->whf);
+    if (const char *pe = getenv("SURFD_DECODER_PRECISION")) d->precision = !strcmp(pe, "fp32") ? 0 : 1;
     for (int l = 0; l < NCBN; ++l) {
         if ((rc = A(&d->gw[l], (size_t)H * d->D))) return rc;
         if ((rc = A(&d->bw[l], (size_t)H * d->D))) return rc;
@@ -581,6 +786,8 @@ static int dec_alloc(surfd_decoder *d) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
     d->allocated = true;
     return SURFD_OK;
@@ -705,11 +912,34 @@ int surfd_decoder_set_param(surfd_decoder *d, const char *key, const void *dev_p
     return SURFD_OK;
 }
 
-int surfd_decoder_finalize(surfd_decoder *d, surfd_stream) {
+int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s) {
     if (!d) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_finalize: null handle");
     for (auto &t : d->params)
         if (!t.is_set) SURFD_FAIL(SURFD_ERR_STATE, "surfd_decoder_finalize: parameter '%s' was never set", t.key.c_str());
+    // f16x2 planes of the forward matrices: one power-of-two scale from max |W|, then split (all on the
+    // stream, no host round trip); the fp32 packs are the source
+    hipStream_t st = as_stream(s);
+    unsigned *maxbits = reinterpret_cast<unsigned *>(d->vecs + VOFF_SC + 2);
+    HIP_TRY(hipMemsetAsync(maxbits, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, st, d->wpack, SZ_FCP + (size_t)2 * NB * SZ_HH, maxbits);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1), 0, st, maxbits, d->vecs + VOFF_SC);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(pack_f16x2_kernel, dim3(128), dim3(256), 0, st, d->wpack + OFF_FCP, KG_E, KS_E, 0, d->vecs + VOFF_SC, d->whf);
+    LAUNCH_CHECK();
+    for (int k = 0; k < NB; ++k)
+        for (int which = 0; which < 2; ++which) {
+            hipLaunchKernelGGL(pack_f16x2_kernel, dim3(1024), dim3(256), 0, st, d->wpack + off_fc(k, which), KG_H, KS_H, 1,
+                               d->vecs + VOFF_SC, d->whf + hf_off_fc(k, which));
+            LAUNCH_CHECK();
+        }
     d->finalized = true;
+    return SURFD_OK;
+}
+
+int surfd_decoder_set_precision(surfd_decoder *d, int mode) {
+    if (!d || (mode != 0 && mode != 1)) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_precision: mode must be 0 (fp32) or 1 (f16x2)");
+    d->precision = mode;
     return SURFD_OK;
 }
 
@@ -744,7 +974,7 @@ int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles
     if (!d->finalized) SURFD_FAIL(SURFD_ERR_STATE, "decoder: parameters not finalized");
     if (sample < 0 || sample >= d->S) SURFD_FAIL(SURFD_ERR_STATE, "decoder: sample %d not bound (%d latents bound)", sample, d->S);
     DecParams P;
-    P.wpack = d->wpack; P.vecs = d->vecs;
+    P.wpack = d->wpack; P.vecs = d->vecs; P.whf = d->whf;
     P.tab = d->tab + (size_t)sample * NCBN * 2 * H;
     P.input_dim = d->input_dim;
     io.emb_dim = d->input_dim;
@@ -754,6 +984,8 @@ int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles
     prof_begin(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
     if (grad)
         hipLaunchKernelGGL(decoder_kernel<true>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
+    else if (d->precision == 1)
+        hipLaunchKernelGGL((decoder_kernel<false, true>), dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     else
         hipLaunchKernelGGL(decoder_kernel<false>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     prof_end(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);

@@ -2,6 +2,8 @@
 against the CPU oracle and the reference-made golden vectors, through the C ABI."""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -48,11 +50,15 @@ def test_library_and_device():
     assert N.lib().surfd_device_count() >= 1
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
 @pytest.mark.parametrize("D", [32, 64])
-def test_decoder_vs_golden(golden, D):
+def test_decoder_vs_golden(golden, D, precision):
+    """Both forward arithmetics (include/surfd_hip.h, surfd_decoder_set_precision) against the reference's
+    own outputs, same tolerances."""
     from surfd_amd.cbndec import make_udf_func
     g = golden(f"g8_decoder_D{D}")
     dec, _ = _decoder(D)
+    dec.set_precision(precision)
     lat = T(g["lat"]).cuda()
     pts = T(g["pts"]).cuda()
     dec.bind_latents(lat)
@@ -61,7 +67,10 @@ def test_decoder_vs_golden(golden, D):
     udf = dec.udf(pts, 0).cpu().numpy()
     np.testing.assert_allclose(udf, g["udf"], rtol=0, atol=1e-6)          # stated tolerance: 1e-6 on [0, 0.1]
     udf2, ng = dec.udf_and_ngrad(pts, 0)
-    np.testing.assert_array_equal(udf2.cpu().numpy(), udf)                    # both kernels share the forward
+    if precision == "fp32":
+        np.testing.assert_array_equal(udf2.cpu().numpy(), udf)                # both kernels share the forward
+    else:                                                                     # gradient kernel stays fp32
+        np.testing.assert_allclose(udf2.cpu().numpy(), udf, rtol=0, atol=2e-7)
     ng = ng.cpu().numpy()
     nz = np.linalg.norm(g["ngrad"], axis=-1) > 0
     _check_directions(_cos(ng, g["ngrad"])[nz])
@@ -88,8 +97,10 @@ def test_decoder_ragged_vs_oracle(n):
     _check_directions(_cos(ng[:m].cpu().numpy(), refg)[nz])
     # tile-position independence: the same point gives the same bits wherever it sits
     perm = torch.randperm(n, generator=g)
+    udf_f = dec.udf(pts.cuda(), 0)                       # forward kernel (f16x2 by default; the gradient kernel is fp32)
+    np.testing.assert_allclose(udf_f.cpu().numpy(), udf.cpu().numpy(), rtol=0, atol=2e-7)
     udf_p = dec.udf(pts[perm].cuda(), 0)
-    np.testing.assert_array_equal(udf_p.cpu().numpy(), udf.cpu().numpy()[perm.numpy()])
+    np.testing.assert_array_equal(udf_p.cpu().numpy(), udf_f.cpu().numpy()[perm.numpy()])
 
 
 def test_decoder_saturation_edge_cases():
@@ -244,8 +255,10 @@ def test_dense_grid_variant():
     udf, grads = get_udf_and_grads(f, (-1, 1), 0.1, 64, 2 ** 16)
     ax = ogrid.axis_coords(64)
     pts = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3).cuda()
-    direct, ng = dec.udf_and_ngrad(pts, 0)
+    direct = dec.udf(pts, 0)                        # forward kernel: what the grid holds, bit for bit
+    udf_g, ng = dec.udf_and_ngrad(pts, 0)           # gradient kernel (fp32 arithmetic)
     assert torch.equal(udf.reshape(-1), direct)
+    assert float((udf_g - direct).abs().max()) < 2e-7
     thr = float(torch.tensor(0.1 - 1e-3, dtype=torch.float32))
     want = direct < thr
     assert torch.equal(grads.reshape(-1, 3)[want], ng[want])
@@ -291,3 +304,23 @@ def test_reference_script_flow_end_to_end(tmp_path):
     for udf, grads in results:
         assert udf.shape == (64, 64, 64) and grads.shape == (64, 64, 64, 3)
         assert float(udf.min()) >= 0.0 and float(udf.max()) <= 0.1 + 1e-6
+
+
+def test_decoder_f16x2_vs_fp32_kernel(golden):
+    """The default split-fp16 forward kernel against the exact-fp32 kernel on the same points: the difference
+    must be of the size of fp32 rounding noise (either kernel differs from an fp64 evaluation by ~1e-6)."""
+    g = golden("g8_decoder_D32")
+    dec, _ = _decoder(32)
+    lat = T(g["lat"]).cuda()
+    pts = (torch.rand(1 << 16, 3, generator=torch.Generator().manual_seed(11)) * 2 - 1).cuda()
+    dec.bind_latents(lat)
+    dec.set_precision("fp32")
+    ref = dec._logits_xyz(pts, 0).cpu().numpy()
+    dec.set_precision("f16x2")
+    out = dec._logits_xyz(pts, 0).cpu().numpy()
+    d = np.abs(out - ref)
+    print("f16x2 vs fp32 kernel: max |dlogit| = %.3e, mean %.3e" % (d.max(), d.mean()))
+    assert d.max() < 1e-5 and d.mean() < 1e-6
+    # saturation instead of inf for absurd inputs (documented range limit of the mode)
+    far = torch.full((64, 3), 3.0e4, device="cuda")
+    assert torch.isfinite(dec._logits_xyz(far, 0)).all()
