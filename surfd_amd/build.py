@@ -20,6 +20,7 @@ SOURCES = ["core.hip", "decoder.hip", "grid.hip", "unet.hip", "sampler.hip"]
 # "fast" contraction the compiler would fuse the separately rounded steps that mirror torch's
 # fp32 op sequence (grid coordinates, posterior updates) into FMAs.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-ffp-contract=off"]
+FLAGS += os.environ.get("SURFD_EXTRA_HIPCC_FLAGS", "").split()      # debugging builds only (e.g. -DSURFD_DEC_STAMPS)
 
 
 def _hipcc() -> str:

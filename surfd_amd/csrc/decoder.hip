@@ -164,41 +164,68 @@ __device__ __forceinline__ void mfma_step_f16x2(const f16x8 (&a)[2][2], const f1
 }
 
 // acc[mt][nt] += A[64 x 16*KS] (split fp16 planes in LDS) * W (two fp16 planes, 4 channel tiles of this wave).
-// One k-step is 24 MFMAs = 768 matrix-pipe cycles; the 8 weight fragments of k-step ks+D-1 and the 4
-// activation fragments of ks+1 are requested before the MFMAs of ks are issued (rotating register
-// stages, no copies), so D-1 k-steps of MFMA time cover the L2 latency.
-template <int KS, int D>
-__device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *Whf, f32x16 (&acc)[2][4], int lane) {
-    static_assert(KS % D == 0 && D % 2 == 0, "k-step count must be a multiple of the (even) pipeline depth");
+// One k-step is 24 MFMAs = 768 matrix-pipe cycles.  The weight stream is software-pipelined ACROSS the
+// GEMMs of a tile: D register stages rotate, stage (ks + D-1) is requested while k-step ks computes, and
+// the last D-1 k-steps of a GEMM already request the first stages of the NEXT matrix (weights do not
+// depend on activations), so the L2 latency at every layer boundary hides behind the epilogue.
+// The 8 weight loads and 4 activation-fragment LDS reads of a k-step are interleaved one per MFMA.
+struct WStages { f16x8 b[4][4][2]; };        // D = 4 stages x 4 channel tiles x 2 planes
+
+template <int KS>
+__device__ __forceinline__ void load_wstage(f16x8 (&dst)[4][2], const _Float16 *Whf, unsigned lofs, int ks) {
+    // uniform base (SGPRs) + 32-bit per-lane byte offset: fragment (nt, ks, plane) at ((nt*KS + ks)*2 + plane) KiB
+    const __attribute__((address_space(1))) char *wb = (const __attribute__((address_space(1))) char *)Whf;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            dst[nt][q] = *reinterpret_cast<const gf16x8 *>(wb + (size_t)(nt * KS * 2048) + (lofs + (unsigned)((ks * 2 + q) * 1024)));
+}
+
+// first D-1 stages of a matrix (once per kernel, before the first tile)
+template <int KS>
+__device__ __forceinline__ void gemm_prefetch_f16x2(WStages &ws, const _Float16 *Whf, int lane) {
+    unsigned lofs = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lofs));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
+}
+
+template <int KS, int KSN>
+__device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *Whf, const _Float16 *Wnext, WStages &ws,
+                                               f32x16 (&acc)[2][4], int lane) {
+    constexpr int D = 4;
+    static_assert(KS % D == 0 && KSN >= D - 1, "k-step count must be a multiple of the pipeline depth");
     const float *a0 = A + (lane & 31) * XS + 4 * (lane >> 5);
     const float *a1 = a0 + 32 * XS;
-    const gf16x8 *w = reinterpret_cast<const gf16x8 *>((const __attribute__((address_space(1))) _Float16 *)Whf) + lane;
-    f16x8 b[D][4][2], x[2][2][2];
-    auto load_w = [&](f16x8 (&dst)[4][2], int ks) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) dst[nt][q] = w[(size_t)((nt * KS + ks) * 2 + q) * 64];
-    };
+    unsigned lofs = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lofs));      // keep the per-fragment offsets 32-bit adds, not hoisted 64-bit addresses
+    f16x8 x[2][2][2];
     auto load_x = [&](f16x8 (&dst)[2][2], int ks) {
         dst[0][0] = *reinterpret_cast<const f16x8 *>(a0 + ks * 8); dst[0][1] = *reinterpret_cast<const f16x8 *>(a0 + 256 + ks * 8);
         dst[1][0] = *reinterpret_cast<const f16x8 *>(a1 + ks * 8); dst[1][1] = *reinterpret_cast<const f16x8 *>(a1 + 256 + ks * 8);
     };
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) load_w(b[d], d);
-    load_x(x[0], 0);
-#pragma unroll 1
-    for (int ks0 = 0; ks0 < KS; ks0 += D) {
+    auto group = [&](int ks0, auto last) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int ks = ks0 + j;
-            load_w(b[(j + D - 1) % D], ks + D - 1 < KS ? ks + D - 1 : KS - 1);     // tail: harmless re-load
-            load_x(x[(j + 1) & 1], ks + 1 < KS ? ks + 1 : KS - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step_f16x2(x[j & 1], b[j], acc);
+            if (decltype(last)::value && j >= 1) load_wstage<KSN>(ws.b[(j + D - 1) % D], Wnext, lofs, j - 1);
+            else load_wstage<KS>(ws.b[(j + D - 1) % D], Whf, lofs, ks + D - 1);
+            load_x(x[(j + 1) & 1], (decltype(last)::value && j == D - 1) ? ks : ks + 1);
+            mfma_step_f16x2(x[j & 1], ws.b[j], acc);
+            // issue order: one memory instruction per MFMA, then the remaining MFMAs
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+    load_x(x[0], 0);
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KS - D; ks0 += D) group(ks0, std::false_type{});
+    group(KS - D, std::true_type{});
 }
 
 // one 32x32 tile: rows = points [32*mt, +32), cols = packed tile `Wp_tile`
@@ -228,6 +255,23 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][4]) {
 __device__ __forceinline__ constexpr int mword(int mt, int nt) { return (mt * 4 + nt) >> 1; }
 __device__ __forceinline__ constexpr int mbit(int mt, int nt, int r) { return ((mt * 4 + nt) & 1) * 16 + r; }
 
+// Optional phase timing of the forward kernel (-DSURFD_DEC_STAMPS, debugging only): shader-clock cycles of
+// workgroup 0 / wave 0 accumulated per phase: 0 fetch+encode, 1 GEMM loops, 2 epilogues, 3 barrier waits, 4 output
+#ifdef SURFD_DEC_STAMPS
+__device__ long long g_dec_stamps[8];
+#define TDECL() long long tacc_[5] = {0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter()
+#define TADD(slot) do { const long long t1_ = __builtin_readcyclecounter(); tacc_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
+#define TBAR() do { TADD(tphase_); __syncthreads(); TADD(3); } while (0)
+#define TPHASE(x) tphase_ = (x)
+#define TFLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 5; ++i_) g_dec_stamps[i_] += tacc_[i_]; g_dec_stamps[5] += 1; } } while (0)
+#else
+#define TDECL()
+#define TADD(slot)
+#define TBAR() __syncthreads()
+#define TPHASE(x)
+#define TFLUSH()
+#endif
+
 template <bool GRAD, bool F16X2 = false>
 __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     static_assert(!(GRAD && F16X2), "the reverse sweep is fp32 only");
@@ -241,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: keeps weight bases in SGPRs
     const long npts = pt_count(io);
     const long ntiles = (npts + TP - 1) / TP;
     // per-lane LDS bases of this wave's accumulator footprint in X (one per point tile): every
@@ -253,29 +298,32 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     lds_u32 *xw0 = (lds_u32 *)(reinterpret_cast<unsigned *>(X) + (4 * (lane >> 5)) * XS + 64 * wave + col);
     lds_u32 *xw1 = xw0 + 32 * XS;
 #define XW(mt, q, r, pl) ((mt) ? xw1 : xw0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (q) + 256 * (pl)]
-    // X <- split(relu(a*(v + b0) + b)) for this wave's accumulator footprint
-    auto store_split = [&](auto has_bias, const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4], const float (&b0)[4]) {
+    // X <- split(min(relu(a*v + b), 65504)) for this wave's accumulator footprint (a, b per channel tile).
+    // Scalar fp32 ops on purpose: packed-f32 ops would need register pairs built from two accumulator
+    // tiles (copies + spills), and this mode has no bitwise contract, so the affine map is one fma.
+    auto store_split = [&](const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4]) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const f32x2 a2 = {sa[2 * q], sa[2 * q + 1]}, b2 = {sb[2 * q], sb[2 * q + 1]}, c2 = {b0[2 * q], b0[2 * q + 1]};
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const f32x2 n2 = {v[mt][2 * q][r], v[mt][2 * q + 1][r]};
-                    f32x2 u;
-                    if constexpr (decltype(has_bias)::value) u = a2 * (n2 + c2) + b2;
-                    else u = a2 * n2 + b2;
-                    u.x = __builtin_amdgcn_fmed3f(u.x, 0.f, 65504.f);
-                    u.y = __builtin_amdgcn_fmed3f(u.y, 0.f, 65504.f);
-                    unsigned hi, lo;
-                    split2(u, hi, lo);
-                    XW(mt, q, r, 0) = hi;
-                    XW(mt, q, r, 1) = lo;
+                    const float u0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]), 0.f, 65504.f);
+                    const float u1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r], sb[2 * q + 1]), 0.f, 65504.f);
+                    const f32x2 u = {u0, u1};
+                    const f16x2 h = __builtin_convertvector(u, f16x2);              // one v_cvt_pk_f16_f32
+                    const f32x2 hf = __builtin_convertvector(h, f32x2);
+                    const f32x2 rr = {u0 - hf.x, u1 - hf.y};
+                    const f16x2 l = __builtin_convertvector(rr, f16x2);
+                    XW(mt, q, r, 0) = __builtin_bit_cast(unsigned, h);
+                    XW(mt, q, r, 1) = __builtin_bit_cast(unsigned, l);
                 }
-        }
     };
 
+    WStages ws;
+    if constexpr (F16X2) gemm_prefetch_f16x2<KS_E>(ws, P.whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, lane);
+
+    TDECL(); int tphase_ = 0; (void)tphase_;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long e0 = tile * TP;
         // re-materialise the arena bases per tile: keeps the compiler from hoisting ~100 derived
@@ -287,7 +335,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
         if constexpr (F16X2) asm volatile("" : "+s"(whf), "+v"(cb), "+v"(xw0), "+v"(xw1));
         // (the asm erases the address space: restore "global" so loads stay global_load, not flat)
         const gfloat *wpack = (const gfloat *)wpack_, *vecs = (const gfloat *)vecs_, *tab = (const gfloat *)tab_;
-        __syncthreads();   // previous tile's readers of PT/LOG/E2/DV are done
+        TPHASE(4);
+        TBAR();   // previous tile's readers of PT/LOG/E2/DV are done
         // ---- 1. fetch points ------------------------------------------------------------
         if (tid < TP) {
             const long e = e0 + tid;
@@ -307,7 +356,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             PT[tid * 4 + 0] = x; PT[tid * 4 + 1] = y; PT[tid * 4 + 2] = z;
             PT[tid * 4 + 3] = __int_as_float(vox);
         }
-        __syncthreads();
+        TPHASE(0);
+        TBAR();
         // ---- 2. positional encoding into E[p][0..63] ---------------------------------------
         if constexpr (!F16X2) {
             const int p = tid >> 2, part = tid & 3;
@@ -359,7 +409,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                 row[256 + i] = lo;
             }
         }
-        __syncthreads();
+        TPHASE(0);
+        TBAR();
         // ---- 3. fc_p -----------------------------------------------------------------------
         f32x16 net[2][4], tmp[2][4];
         unsigned msk[GRAD ? NCBN : 1][4];
@@ -373,10 +424,11 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
         auto scl = [](float v, float f) { if constexpr (F16X2) return v * f; else return v; };
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
+            const std::conditional_t<F16X2, unsigned, int> c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
             nsa[nt] = scl(tab[c], winv); nsb[nt] = tab[H + c];
         }
-        if constexpr (F16X2) gemm_2x4_f16x2<KS_E, 4>(X, whf + (size_t)(4 * wave) * KS_E * 2 * 512, net, lane);
+        if constexpr (F16X2) gemm_2x4_f16x2<KS_E, KS_H>(X, whf + (size_t)(4 * wave_u) * KS_E * 2 * 512,
+                                                      whf + hf_off_fc(0, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, net, lane);
         else gemm_2x4<KG_E>(E, ES, wpack + OFF_FCP + (size_t)(4 * wave) * KG_E * 256, net, lane);
         {
             float bias[4];
@@ -389,7 +441,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) net[mt][nt][r] += bias[nt];
         }
-        __syncthreads();   // E (aliasing X) fully consumed
+        TPHASE(1);
+        TBAR();   // E (aliasing X) fully consumed
         // ---- 4. residual blocks ---------------------------------------------------------------
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -400,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                 for (int nt = 0; nt < 4; ++nt) { sa[nt] = nsa[nt]; sb[nt] = nsb[nt]; }
                 if constexpr (GRAD) { msk[2 * k][0] = msk[2 * k][1] = msk[2 * k][2] = msk[2 * k][3] = 0u; }
                 if constexpr (F16X2) {
-                    store_split(std::false_type{}, net, sa, sb, sb);
+                    store_split(net, sa, sb);
                 } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -414,19 +467,22 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                         }
                 }
             }
-            __syncthreads();
+            TPHASE(2);
+            TBAR();
             zero_acc(tmp);
             float sa1[4], sb1[4], bias0[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
+                const std::conditional_t<F16X2, unsigned, int> c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
                 sa1[nt] = scl(tab[(2 * k + 1) * 2 * H + c], winv);
                 sb1[nt] = tab[(2 * k + 1) * 2 * H + H + c];
                 bias0[nt] = scl(vecs[voff_bfc(k, 0) + c], wsc);
             }
-            if constexpr (F16X2) gemm_2x4_f16x2<KS_H, 4>(X, whf + hf_off_fc(k, 0) + (size_t)(4 * wave) * KS_H * 2 * 512, tmp, lane);
+            if constexpr (F16X2) gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fc(k, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
+                                                          whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, tmp, lane);
             else gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 0) + (size_t)(4 * wave) * KG_H * 256, tmp, lane);
-            __syncthreads();
+            TPHASE(1);
+            TBAR();
             // X <- relu(a*(tmp + bias0) + b), layer 2k+1
             {
                 float sa[4], sb[4], bias[4];
@@ -434,7 +490,10 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                 for (int nt = 0; nt < 4; ++nt) { sa[nt] = sa1[nt]; sb[nt] = sb1[nt]; bias[nt] = bias0[nt]; }
                 if constexpr (GRAD) { msk[2 * k + 1][0] = msk[2 * k + 1][1] = msk[2 * k + 1][2] = msk[2 * k + 1][3] = 0u; }
                 if constexpr (F16X2) {
-                    store_split(std::true_type{}, tmp, sa, sb, bias);
+                    float sbb[4];      // a*(t + bias) + b = a*t + (a*bias + b)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) sbb[nt] = __builtin_fmaf(sa[nt], bias[nt], sb[nt]);
+                    store_split(tmp, sa, sbb);
                 } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -448,17 +507,23 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                         }
                 }
             }
-            __syncthreads();
+            TPHASE(2);
+            TBAR();
             // net += fc_1(X) + bias1   (residual accumulates straight into the MFMA C operand)
             float bias1[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
+                const std::conditional_t<F16X2, unsigned, int> c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
                 bias1[nt] = scl(vecs[voff_bfc(k, 1) + c], wsc);
                 nsa[nt] = scl(tab[(2 * k + 2) * 2 * H + c], winv);   // next block's first CBN (or the final one)
                 nsb[nt] = tab[(2 * k + 2) * 2 * H + H + c];
             }
-            if constexpr (F16X2) gemm_2x4_f16x2<KS_H, 4>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave) * KS_H * 2 * 512, net, lane);
+            if constexpr (F16X2) {
+                if (k + 1 < NB) gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
+                                                           whf + hf_off_fc(k + 1 < NB ? k + 1 : 0, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, net, lane);
+                else gemm_2x4_f16x2<KS_H, KS_E>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
+                                                whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, ws, net, lane);     // next tile's fc_p
+            }
             else gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 1) + (size_t)(4 * wave) * KG_H * 256, net, lane);
             {
                 float bias[4];
@@ -471,7 +536,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) net[mt][nt][r] += bias[nt];
             }
-            __syncthreads();
+            TPHASE(1);
+            TBAR();
         }
         // ---- 5. final CBN + ReLU + fc_out (512 -> 1) -----------------------------------------
         float wo[4], a10[4];
@@ -479,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             float sb[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
+                const std::conditional_t<F16X2, unsigned, int> c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
                 a10[nt] = nsa[nt];
                 sb[nt] = nsb[nt];
                 wo[nt] = vecs[VOFF_WOUT + c];
@@ -496,7 +562,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                         XAT(mt, nt, r) = fmaxf(u, 0.f) * wo[nt];
                     }
         }
-        __syncthreads();
+        TPHASE(2);
+        TBAR();
         {
             const float bo = vecs[VOFF_BOUT];
             for (int pp = 0; pp < TP / 4; ++pp) {
@@ -509,8 +576,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                 if (lane == 0) LOG[p] = sacc + bo;
             }
         }
-        __syncthreads();
+        TBAR();
 
+        TPHASE(4);
         if constexpr (!GRAD) {
             if (tid < TP) {          // exactly wave 0: all 64 lanes reach the aggregated append
                 const long e = e0 + tid;
@@ -647,6 +715,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             }
         }
     }
+    TFLUSH();
 }
 
 #undef XAT
@@ -936,6 +1005,15 @@ int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s) {
     d->finalized = true;
     return SURFD_OK;
 }
+
+#ifdef SURFD_DEC_STAMPS
+extern "C" int surfd_decoder_debug_stamps(long long *out8, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dec_stamps), 8 * sizeof(long long)));
+    if (reset) { long long z[8] = {}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), z, sizeof(z))); }
+    return SURFD_OK;
+}
+#endif
 
 int surfd_decoder_set_precision(surfd_decoder *d, int mode) {
     if (!d || (mode != 0 && mode != 1)) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_precision: mode must be 0 (fp32) or 1 (f16x2)");
