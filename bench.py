@@ -8,8 +8,13 @@ One "step" = one pass of the hot path over one batch of synthetic shapes on ever
 surfd_amd.synth (no checkpoints exist offline); noise is seeded per global shape index, so a
 shape's result does not depend on how shapes are sharded over ranks.
 
-    python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus 1 --steps 6 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Batches are software-pipelined (--pipeline 1, default): the reverse loop of batch s+1 — a chain of ~115 000
+dependent, latency-bound launches — runs on its own HIP stream on half of the CUs while the grids of batch s
+(matrix-pipe/power bound) are evaluated on the other half; every one of the K batches runs start to finish
+inside the timed region (pipeline fill and drain included).  --pipeline 0 runs loop then grids on one stream.
 
 Multi-GPU: shapes are independent -> each rank owns its own B shapes (weak scaling), no
 data-path collective; ranks meet only at the timing barriers.
@@ -39,7 +44,7 @@ F16_MFMA_PEAK_TF = 2500.0     # MI355X dense fp16/bf16 matrix peak (same guide; 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="shapes per GPU per step")
     ap.add_argument("--resolution", type=int, default=512)
@@ -47,6 +52,11 @@ def parse():
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--decoder-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="forward decoder kernel arithmetic (include/surfd_hip.h: surfd_decoder_set_precision)")
+    ap.add_argument("--decoder-blocks", type=int, default=128,
+                    help="with --pipeline 1: persistent decoder workgroups per launch while the next batch's reverse loop "
+                         "runs on the remaining CUs (the last batch's grids, with nothing left to overlap, use every CU)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1: overlap the reverse loop of batch s+1 with the grid evaluation of batch s on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -148,24 +158,58 @@ def main():
     grads = [torch.empty(N, N, N, 3, device="cuda") for _ in range(B)]
     stats = []
 
-    def one_step(collect=False):
-        lat = diffusion.p_sample_loop(model, (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}},
-                                      noise_stream=noise, fused=True)
+    def sample_latents():
+        return diffusion.p_sample_loop(model, (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}},
+                                       noise_stream=noise, fused=True)
+
+    def fill_grids(lat, collect=False):
         dec.bind_latents(lat.reshape(B, a.latent))
         for k in range(B):
             f = make_udf_func(dec, lat[k], sample=k)
             filler.fill_grid(f, 2 ** 16, out=(udf[k], grads[k]), stats=collect)
             if collect:
                 stats.append(filler.last_stats)
+
+    def one_step(collect=False):
+        lat = sample_latents()
+        fill_grids(lat, collect)
         return lat
 
-    for _ in range(a.warmup):
-        one_step()
+    loop_stream, dec_stream = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run_steps(k_steps):
+        """k_steps full passes (every batch: reverse loop + 8 grids), start to finish.  Pipelined mode: batch
+        s+1's reverse loop (latency-bound, few CUs) runs on its own stream while batch s's grids (matrix-pipe
+        bound) are evaluated; shapes are independent, so this is the steady state of a sampling service."""
+        if not a.pipeline:
+            for _ in range(k_steps):
+                one_step()
+            return
+        cur = torch.cuda.current_stream()
+        loop_stream.wait_stream(cur)
+        dec_stream.wait_stream(cur)
+        lat = [None, None]
+        ev_loop = [torch.cuda.Event(), torch.cuda.Event()]
+        for s in range(k_steps + 1):
+            if s >= 1:                                   # grids of batch s-1 (enqueued first: the loop call below
+                with torch.cuda.stream(dec_stream):      # blocks the host until the previous loop has drained)
+                    dec_stream.wait_event(ev_loop[(s - 1) % 2])
+                    dec.set_grid_blocks(a.decoder_blocks if s < k_steps else 0)
+                    fill_grids(lat[(s - 1) % 2])
+            if s < k_steps:
+                with torch.cuda.stream(loop_stream):
+                    x = sample_latents()
+                    x.record_stream(dec_stream)
+                    lat[s % 2] = x
+                    ev_loop[s % 2].record(loop_stream)
+        cur.wait_stream(loop_stream)
+        cur.wait_stream(dec_stream)
+
+    run_steps(a.warmup)
     barrier(world)
     L.surfd_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
+    run_steps(a.steps)
     barrier(world)
     elapsed = time.perf_counter() - t0
     L.surfd_profile_enable(0)
@@ -175,6 +219,7 @@ def main():
         Nn.check(L.surfd_profile_read(kind, C.byref(n), C.byref(ms)))
         prof[name] = (n.value, ms.value)
     # workload counters (one extra, untimed pass; the counters are deterministic)
+    dec.set_grid_blocks(0)
     one_step(collect=True)
     torch.cuda.synchronize()
     n_fwd = sum(sum(s["fwd_per_level"]) for s in stats) / B
@@ -212,11 +257,17 @@ def main():
                    "shapes_per_gpu": B, "resolution": N, "diffusion_steps": T,
                    "decoder_fwd_queries_per_shape": n_fwd, "decoder_grad_queries_per_shape": n_grad,
                    "decoder_precision": a.decoder_precision,
+                   "pipeline": ("reverse loop of batch s+1 overlaps the grids of batch s on two HIP streams; the decoder "
+                                f"kernels run on {a.decoder_blocks} of the CUs while a loop is in flight and on all of them "
+                                "for the last batch; every batch runs start to finish inside the timed region")
+                               if a.pipeline else "none (loop then grids, one stream)",
                    "parallelism": f"shape-parallel x{world}, no data-path collective"},
         "roofline": {"kernel": kname, "bound": "mfma",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None, "launches": fwd_launches, "avg_launch_ms": fwd_ms / max(fwd_launches, 1),
                      "flop_per_point": FWD_FLOP, "algorithmic_tflops": algorithmic,
+                     "cus": (f"{a.decoder_blocks} of 256 for {a.steps - 1} of {a.steps} batches (the rest run the next batch's "
+                             "reverse loop), 256 for the last; peak is the whole chip's") if a.pipeline else "256",
                      "mfma_flop_per_point": (3 if a.decoder_precision == "f16x2" else 1) * FWD_FLOP},
         "breakdown_ms_per_step": {"reverse_loop": prof["loop"][1] / a.steps, "decoder_fwd": fwd_ms / a.steps,
                                   "decoder_fwd_bwd": grad_ms / a.steps,

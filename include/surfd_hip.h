@@ -141,6 +141,10 @@ int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s);
  * The gradient kernel (surfd_decoder_udf_grad) always runs in fp32.  The initial mode can also be set with
  * SURFD_DECODER_PRECISION=fp32|f16x2. */
 int surfd_decoder_set_precision(surfd_decoder *d, int mode);
+/* The decoder kernels are persistent: `blocks` workgroups (one per CU, LDS-limited) loop over the point tiles.
+ * 0 (default) = every CU.  A smaller value leaves CUs free for work on another stream (bench.py overlaps the
+ * reverse loop of the next batch with the grid evaluation of the current one this way). */
+int surfd_decoder_set_grid_blocks(surfd_decoder *d, int blocks);
 /* lat[S,D]: computes the per-sample conditional-BN scale/shift tables [S,11,2,H]
  * (the 22 per-point Conv1d(D->H) of cbndec.py:74-79 collapse to this when one latent is
  * broadcast to all points, cbndec.py:131-132). */

@@ -62,6 +62,7 @@ _SIGS = {
     "surfd_decoder_set_param": (C.c_int, [_P, C.c_char_p, _P, c_i64p, C.c_int, _P]),
     "surfd_decoder_finalize": (C.c_int, [_P, _P]),
     "surfd_decoder_set_precision": (C.c_int, [_P, C.c_int]),
+    "surfd_decoder_set_grid_blocks": (C.c_int, [_P, C.c_int]),
     "surfd_decoder_bind_latents": (C.c_int, [_P, _P, C.c_int, _P]),
     "surfd_decoder_logits_emb": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, _P]),
     "surfd_decoder_udf": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, _P, _P]),

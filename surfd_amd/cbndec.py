@@ -175,6 +175,11 @@ class CbnDecoder(nn.Module):
         L, h = self._native()
         N.check(L.surfd_decoder_set_precision(h, {"fp32": 0, "f16x2": 1}[mode]))
 
+    def set_grid_blocks(self, blocks: int) -> None:
+        """Persistent workgroups per decoder launch (0 = one per CU); fewer leaves CUs to other streams."""
+        L, h = self._native()
+        N.check(L.surfd_decoder_set_grid_blocks(h, int(blocks)))
+
     def bind_latents(self, latents: Tensor) -> None:
         """latents [S, D]: precompute the per-sample conditional-BN tables once."""
         L, h = self._native()

@@ -811,6 +811,7 @@ struct surfd_decoder {
     float *tab = nullptr;
     int S = 0, tab_cap = 0;
     int num_cus = 256;
+    int grid_blocks = 0;              // persistent workgroups per launch; 0 = one per CU
     std::vector<void *> allocs;
 };
 
@@ -1015,6 +1016,12 @@ extern "C" int surfd_decoder_debug_stamps(long long *out8, int reset) {
 }
 #endif
 
+int surfd_decoder_set_grid_blocks(surfd_decoder *d, int blocks) {
+    if (!d || blocks < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_grid_blocks: bad argument");
+    d->grid_blocks = blocks;
+    return SURFD_OK;
+}
+
 int surfd_decoder_set_precision(surfd_decoder *d, int mode) {
     if (!d || (mode != 0 && mode != 1)) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_set_precision: mode must be 0 (fp32) or 1 (f16x2)");
     d->precision = mode;
@@ -1057,7 +1064,7 @@ int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles
     P.input_dim = d->input_dim;
     io.emb_dim = d->input_dim;
     // one workgroup per CU (LDS-limited); a device-side count is handled by the tile loop
-    long blocks = d->num_cus;
+    long blocks = d->grid_blocks > 0 ? std::min(d->grid_blocks, d->num_cus) : d->num_cus;
     if (ntiles_hint >= 0) blocks = std::min<long>(blocks, std::max<long>(ntiles_hint, 1));
     prof_begin(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
     if (grad)
