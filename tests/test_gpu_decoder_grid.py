@@ -182,6 +182,26 @@ def test_grid_callback_analytic_bit_exact(golden, N):
         np.testing.assert_allclose(grads.cpu().numpy(), g["N64_grads_f16"].astype(np.float32), atol=1e-3)
 
 
+def test_grid_callback_analytic_512_counts():
+    """BASELINE's full grid size.  The reference's own run of GridFiller(512) on the analytic field
+     evaluates [32768, 229376, 91350, 346066, 1349754] points per level, 746008 gradient
+    points, and its udf grid sums to 13 017 254.6665; the index kernels must reproduce the counts exactly."""
+    from surfd_amd.meshudf import GridFiller
+
+    def field(c):
+        return ogrid.analytic_field(c.cpu()).cuda()
+
+    gf = GridFiller(512)
+    udf, grads = gf.fill_grid(field, 2 ** 30)
+    assert gf.last_stats["fwd_per_level"] == [32768, 229376, 91350, 346066, 1349754]
+    assert gf.last_stats["grad"] == 746008
+    assert float(udf.double().sum()) == pytest.approx(13017254.6665, rel=1e-7)
+    has = grads.abs().sum(-1) > 0
+    assert int(has.sum()) <= 746008 and bool((udf[has] < 2.5 * 2.0 / 512).all())
+    del udf, grads
+    torch.cuda.empty_cache()
+
+
 def test_grid_native_vs_golden_and_callback(golden):
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
