@@ -175,35 +175,19 @@ def main():
         fill_grids(lat, collect)
         return lat
 
-    loop_stream, dec_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    from surfd_amd.parallel import BatchPipeline
+    pipe = BatchPipeline(dec, lambda s: sample_latents(), lambda s, lat: fill_grids(lat), a.decoder_blocks)
 
     def run_steps(k_steps):
-        """k_steps full passes (every batch: reverse loop + 8 grids), start to finish.  Pipelined mode: batch
-        s+1's reverse loop (latency-bound, few CUs) runs on its own stream while batch s's grids (matrix-pipe
-        bound) are evaluated; shapes are independent, so this is the steady state of a sampling service."""
+        """k_steps full passes (every batch: reverse loop + 8 grids), start to finish.  Pipelined mode
+        (surfd_amd.parallel.BatchPipeline): batch s+1's reverse loop (latency-bound, few CUs) runs on its own
+        stream while batch s's grids (matrix-pipe bound) are evaluated; shapes are independent, so this is the
+        steady state of a sampling service."""
         if not a.pipeline:
             for _ in range(k_steps):
                 one_step()
-            return
-        cur = torch.cuda.current_stream()
-        loop_stream.wait_stream(cur)
-        dec_stream.wait_stream(cur)
-        lat = [None, None]
-        ev_loop = [torch.cuda.Event(), torch.cuda.Event()]
-        for s in range(k_steps + 1):
-            if s >= 1:                                   # grids of batch s-1 (enqueued first: the loop call below
-                with torch.cuda.stream(dec_stream):      # blocks the host until the previous loop has drained)
-                    dec_stream.wait_event(ev_loop[(s - 1) % 2])
-                    dec.set_grid_blocks(a.decoder_blocks if s < k_steps else 0)
-                    fill_grids(lat[(s - 1) % 2])
-            if s < k_steps:
-                with torch.cuda.stream(loop_stream):
-                    x = sample_latents()
-                    x.record_stream(dec_stream)
-                    lat[s % 2] = x
-                    ev_loop[s % 2].record(loop_stream)
-        cur.wait_stream(loop_stream)
-        cur.wait_stream(dec_stream)
+        elif k_steps:
+            pipe.run(k_steps)
 
     run_steps(a.warmup)
     barrier(world)

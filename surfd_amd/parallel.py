@@ -120,3 +120,49 @@ class ShardedField:
         from .meshudf import sample_grads
         fn = self.grad_func or (lambda p: sample_grads(self.udf_func, p, max_batch))
         return self._scatter_gather(fn, pts, 3)
+
+
+class BatchPipeline:
+    """Software pipeline over independent batches on ONE GPU: the reverse loop of batch s+1 — a chain of
+    ~115 dependent, latency-bound launches per denoiser evaluation — runs on its own HIP stream while the
+    grids of batch s (matrix-pipe bound) are evaluated on another.  The decoder kernels are persistent (one
+    workgroup per CU), so the chip is split simply by their grid size (`CbnDecoder.set_grid_blocks`): while a
+    loop is in flight they take `decoder_blocks` CUs, for the last batch (nothing left to overlap) all of
+    them.  Results are identical to running the batches one after the other (tests/test_gpu_unet.py).
+
+        pipe = BatchPipeline(decoder, sample_fn, fill_fn, decoder_blocks=128)
+        pipe.run(n_batches)
+
+    sample_fn(s) -> latents        enqueues batch s's reverse loop on the current stream
+    fill_fn(s, latents) -> None    enqueues batch s's grid evaluation on the current stream
+    """
+
+    def __init__(self, decoder, sample_fn, fill_fn, decoder_blocks: int = 128):
+        self.decoder, self.sample_fn, self.fill_fn = decoder, sample_fn, fill_fn
+        self.decoder_blocks = int(decoder_blocks)
+        self.loop_stream = torch.cuda.Stream()
+        self.fill_stream = torch.cuda.Stream()
+
+    def run(self, n_batches: int) -> None:
+        cur = torch.cuda.current_stream()
+        self.loop_stream.wait_stream(cur)
+        self.fill_stream.wait_stream(cur)
+        lat = [None, None]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        try:
+            for s in range(n_batches + 1):
+                if s >= 1:      # grids of batch s-1: enqueued before the next loop call, which may block the host
+                    with torch.cuda.stream(self.fill_stream):
+                        self.fill_stream.wait_event(done[(s - 1) % 2])
+                        self.decoder.set_grid_blocks(self.decoder_blocks if s < n_batches else 0)
+                        self.fill_fn(s - 1, lat[(s - 1) % 2])
+                if s < n_batches:
+                    with torch.cuda.stream(self.loop_stream):
+                        x = self.sample_fn(s)
+                        x.record_stream(self.fill_stream)
+                        lat[s % 2] = x
+                        done[s % 2].record(self.loop_stream)
+        finally:
+            self.decoder.set_grid_blocks(0)
+            cur.wait_stream(self.loop_stream)
+            cur.wait_stream(self.fill_stream)

@@ -228,3 +228,41 @@ def test_empty_and_single_inputs():
     assert u.shape == (0,) and g.shape == (0, 3)
     with pytest.raises(RuntimeError, match="not bound"):
         dec.udf(torch.zeros(4, 3).cuda(), 5)                         # latent index outside what was bound
+
+
+def test_batch_pipeline_matches_sequential():
+    """surfd_amd.parallel.BatchPipeline: the next batch's reverse loop on one stream while the previous batch's
+    grids are evaluated on another (decoder on part of the CUs) must return the same bits as running the
+    batches one after the other."""
+    from surfd_amd.cbndec import CbnDecoder, make_udf_func
+    from surfd_amd.meshudf import GridFiller
+    from surfd_amd.parallel import BatchPipeline
+    from surfd_amd.spec import DecoderConfig
+    model, _, _ = _model("no_cond")
+    _, dd, _ = _model("no_cond", "ddim20")
+    dec = CbnDecoder(63, 32, 512, 5)
+    dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig(latent_dim=32)), strict=True)
+    dec = dec.cuda().eval()
+    B, N, nb = 2, 64, 3
+    filler = GridFiller(N)
+    noise = [synth.synth_noise_batch(20, s * B, B, 32).cuda() for s in range(nb)]
+
+    def sample(s):
+        return dd.ddim_sample_loop(model, (B, 1, 32), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise[s], fused=True)
+
+    def make_fill(store):
+        def fill(s, lat):
+            dec.bind_latents(lat.reshape(B, 32))
+            for k in range(B):
+                store[(s, k)] = filler.fill_grid(make_udf_func(dec, lat[k], sample=k), 2 ** 16, stats=False)
+        return fill
+
+    seq, pip = {}, {}
+    for s in range(nb):
+        make_fill(seq)(s, sample(s))
+    torch.cuda.synchronize()
+    BatchPipeline(dec, sample, make_fill(pip), decoder_blocks=96).run(nb)
+    torch.cuda.synchronize()
+    assert set(seq) == set(pip)
+    for key in seq:
+        assert torch.equal(seq[key][0], pip[key][0]) and torch.equal(seq[key][1], pip[key][1]), key
