@@ -85,6 +85,19 @@ int surfd_unet_finalize(surfd_unet *u, surfd_stream s);
 int surfd_unet_forward(surfd_unet *u, const float *x, const int64_t *t, const float *ctx,
                        const int64_t *cls, float *out, int B, int L, surfd_stream s);
 
+/* Arithmetic of the denoiser's convolutions (every Conv1d of openaimodel.py ResBlock / AttentionBlock /
+ * Downsample / Upsample / head; the embedding Linears always run in fp32):
+ * 1 = "f16x2" (default): operands split into two fp16 terms, three products on the fp16 matrix pipe, fp32
+ *     accumulation (same scheme as surfd_decoder_set_precision); operands outside +-65504 are clamped and
+ *     counted (surfd_unet_saturation_count).  0 = "fp32": exact v_mfma_f32_32x32x2_f32, no range limit.
+ * The initial mode can also be set with SURFD_UNET_PRECISION=fp32|f16x2. */
+int surfd_unet_set_precision(surfd_unet *u, int mode);
+/* host-sync: number of workgroups of the f16x2 conv kernel that had to clamp an operand to the fp16 range since the
+ * last reset (0 = every evaluation so far was inside the range the mode is exact for) */
+int surfd_unet_saturation_count(surfd_unet *u, int reset, int64_t *count, surfd_stream s);
+/* developer aid: op >= 0 restricts the f16x2 kernel to that one conv op of the plan (the others run fp32); -1 lifts it */
+int surfd_unet_debug_only_op(surfd_unet *u, int op);
+
 /* ------------------------------------------------------------------------------------ */
 /* Reverse loop: p_sample_loop / ddim_sample_loop                                       */
 /* (diffusion/gaussian_diffusion.py:570-708, 858-972; diffusion/respace.py:63-132).      */

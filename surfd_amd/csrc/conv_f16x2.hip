@@ -1,0 +1,668 @@
+// Split-fp16 ("f16x2") convolution kernel of the latent denoiser (reference models/openaimodel.py:255-275
+// ResBlock, :318-324 AttentionBlock projections, :134-160 Downsample, :91-119 Upsample, :682-686 head) for
+// gfx950 — the kernel the reverse loop spends its time in.
+//
+// Same implicit GEMM as conv_kernel (unet.hip): Out[Cout x (b,l)] = W[Cout x K] * im2col(act(GN(x))), K ordered
+// (segment, K block, tap, channel), with GroupNorm32 + SiLU fused into the LDS staging, the 1x1 skip conv as a
+// second K segment and bias / timestep-embedding / residual in the epilogue.  What differs:
+//
+//  * arithmetic: every fp32 operand is split into two fp16 terms (x = xh + xl, |x - xh - xl| <= 2^-22 |x|);
+//    the three significant products xh*wh + xh*wl + xl*wh run on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate)
+//    with fp32 accumulation in three independent accumulators.  Weights are multiplied by one power of two per
+//    layer (max |W| * SC in [256, 512)) before the split so the low terms stay normal; SC is folded back exactly
+//    in the epilogue.  Operands are clamped to +-65504 (fp16 range); a device counter records every workgroup
+//    that had to clamp (surfd_unet_saturation_count) — precision mode 0 runs the exact fp32 kernel instead.
+//  * ONE small kernel for every layer shape (operand length 4..32; a second instantiation for 64): the fp32
+//    family is 7 x 25-50 KB of once-executed straight-line code that misses the instruction cache on every
+//    launch of the latency-bound loop.
+//  * the weight stream is a register ring that runs ACROSS K blocks (weights of the next block are requested
+//    during the last MFMAs of the current one), and the raw operand of the next K block is requested before the
+//    MFMAs of the current one.
+//  * blockIdx -> (tile, batch chunk, K slice) is XCD-aware: all batch chunks that stream the same weight slice
+//    run on one XCD (block b runs on XCD b % 8), so a slice leaves HBM once and is re-read from that XCD's L2.
+#include "common.h"
+#include "unet_api.h"
+#include "unet_plan.h"
+#include <string.h>
+#include <stdlib.h>
+#include <algorithm>
+
+namespace surfd {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16x8 __attribute__((address_space(1))) gf16x8;
+
+struct Seg2 {
+    const float *x;        // source view (channel offset applied)
+    long bstride;          // floats between batch entries
+    const float *gamma, *beta;
+    int C, Lin, log2Lin;
+    int taps, stride, ups, gn, act;
+    int blk, blkp, nblk;   // channels per K block (= staged chunk), padded to 16, number of blocks
+    int k16_off;           // first k16 step of the segment
+    int gs;                // channels per GroupNorm group
+};
+
+struct Conv2Args {
+    Seg2 seg[2];
+    int nseg;
+    const _Float16 *whf;   // [ntiles][KS16][2 planes][64 lanes][8]
+    int KS16;
+    const float *sc;       // {SC, 1/SC}
+    const float *bias;     // [Cout]
+    const float *emb;      // emb[b * emb_bstride + co] or null
+    long emb_bstride;
+    const float *res;      // res[b * res_bstride + co * Lout + l] or null
+    long res_bstride;
+    float *out;
+    long out_bstride;
+    int Cout, Lout, log2Lout, B;
+    int bchunk, Lsl, cs;   // batch entries per workgroup, slab positions per batch entry, slab row stride (halfs)
+    int plane;             // halfs between the high and the low plane of the slab
+    int off_ex, off_red;   // byte offsets of the GroupNorm exchange area / reduction scratch in LDS
+    int ntiles, nby, KS;
+    float *part;           // split-K partial tiles [KS][nby][ntiles][part_stride]
+    int part_stride;
+    int *counters;         // [nby][ntiles], zero between launches
+    const int *step_ptr;   // device loop counter (embedding rows advance by emb_step_stride per step) or null
+    long emb_step_stride;
+    unsigned *sat;         // saturation counter
+};
+
+constexpr int C2_U = 4;    // k16 steps per ring stage
+constexpr int C2_D = 3;    // ring stages (24 x 1 KB fragments in flight per wave)
+
+__device__ __forceinline__ float silu2(float v) { return v * __frcp_rn(1.f + __expf(-v)); }
+
+__device__ __forceinline__ void lds_bar() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// VEC: float4 registers a thread holds while staging its channel (8: operand rows of 4..32 positions,
+// nb * Lin <= 32; 16: 64 positions).  PREF: request the next K block's operand before the current MFMAs.
+template <int VEC, bool PREF>
+__global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
+    float *ex_mean = reinterpret_cast<float *>(lds_raw + A.off_ex);     // [VEC][256]
+    float *ex_m2 = ex_mean + VEC * 256;                                 // [VEC][256]
+    float *gstat = ex_m2 + VEC * 256;                                   // [nb * groups][2]
+    float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- XCD-aware decode: group g = (tile, K slice); every batch chunk of a group on XCD g % 8 ----
+    int tile, by, kz;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int j = idx / A.nby;
+        by = idx - j * A.nby;
+        const int g = xcd + 8 * j;
+        if (g >= A.ntiles * A.KS) return;
+        tile = g / A.KS;
+        kz = g - tile * A.KS;
+    }
+    const int b0 = by * A.bchunk;
+    const int nb = min(A.bchunk, A.B - b0);
+    const int M = nb * A.Lout;
+    const int nct = (M + 31) >> 5;                    // 1 or 2 column tiles (host guarantees M <= 64)
+    const int log2kp = (nct == 1) ? 2 : 1;            // k-parts: 4 or 2 waves share a column tile
+    const int KP = 1 << log2kp;
+    const int ct = (nct == 1) ? 0 : (wave & 1);
+    const int kpart = (nct == 1) ? wave : (wave >> 1);
+    int colb, coll;
+    {
+        int m = ct * 32 + (lane & 31);
+        if (m >= M) m = 0;
+        colb = m >> A.log2Lout;
+        coll = m & (A.Lout - 1);
+    }
+    const int nblk0 = A.seg[0].nblk;
+    const int nch = nblk0 + (A.nseg > 1 ? A.seg[1].nblk : 0);
+    const int cs = A.cs, plane = A.plane;
+    const float inv_sc = A.sc[1];
+
+    f32x16 acc_hh, acc_hl, acc_lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_hh[r] = 0.f; acc_hl[r] = 0.f; acc_lh[r] = 0.f; }
+
+    // ---- weight stream state of one K block for this wave ------------------------------------------
+    struct WS { const _Float16 *base; int it_beg, it_end, ngroups, nk; };
+    auto make_ws = [&](int ch) -> WS {
+        const int s = ch >= nblk0 ? 1 : 0;
+        const int bi = ch - (s ? nblk0 : 0);
+        const int nk = A.seg[s].blkp >> 4;
+        const int iters = A.seg[s].taps * nk;
+        const int per = (iters + KP - 1) >> log2kp;
+        WS w;
+        w.nk = nk;
+        w.it_beg = kpart * per;
+        w.it_end = min(iters, w.it_beg + per);
+        const int n = max(w.it_end - w.it_beg, 0);
+        w.ngroups = (n + C2_U - 1) / C2_U;
+        w.base = A.whf + ((size_t)tile * A.KS16 + A.seg[s].k16_off + (size_t)bi * iters) * 1024 + lane * 8;
+        return w;
+    };
+    f16x8 ring[C2_D][C2_U][2];
+    auto load_group = [&](f16x8 (&dst)[C2_U][2], const WS &w, int g) {
+#pragma unroll
+        for (int u = 0; u < C2_U; ++u) {
+            const int it = min(w.it_beg + g * C2_U + u, w.it_end - 1);
+            const gf16x8 *p = (const gf16x8 *)(w.base + (size_t)it * 1024);
+            dst[u][0] = p[0];
+            dst[u][1] = p[64];          // low plane: +512 halfs
+        }
+    };
+
+    // ---- raw operand of one K block: thread <-> channel, VEC float4 covering (batch row, position) ----
+    auto issue_operand = [&](int ch, f32x4 (&v)[VEC]) {
+        const int s = ch >= nblk0 ? 1 : 0;
+        const int bi = ch - (s ? nblk0 : 0);
+        const int lv = A.seg[s].log2Lin - 2;          // log2(float4 per row)
+        const int Lin = A.seg[s].Lin;
+        const int cg = bi * A.seg[s].blk + tid;
+        const bool cok = tid < A.seg[s].blk;
+        const float *src = A.seg[s].x + (long)cg * Lin;
+        const long bstride = A.seg[s].bstride;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int i = j >> lv, jj = j & ((1 << lv) - 1);
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cok && i < nb) v[j] = *reinterpret_cast<const f32x4 *>(src + (b0 + i) * bstride + 4 * jj);
+        }
+    };
+
+    int ch = kz;
+    WS cur = make_ws(ch);
+    f32x4 v[VEC];
+    issue_operand(ch, v);
+#pragma unroll
+    for (int d = 0; d < C2_D; ++d)
+        if (d < cur.ngroups) load_group(ring[d], cur, d);
+
+    // ---- epilogue operands (bias + per-(step, sample) embedding + residual), requested now, used at the end ----
+    float pre_add[16];
+    {
+        const float *embp = A.emb;
+        if (embp && A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
+        const int m = ct * 32 + (lane & 31);
+        const bool mok = kpart == 0 && m < M;
+        const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = tile * 32 + frag_row(r, lane);
+            float t = 0.f;
+            if (mok && co < A.Cout) {
+                t = A.bias[co];
+                if (embp) t += embp[b * A.emb_bstride + co];
+                if (A.res) t += A.res[b * A.res_bstride + (long)co * A.Lout + l];
+            }
+            pre_add[r] = t;
+        }
+    }
+    bool saturated = false;
+
+    while (true) {
+        // =========================== stage K block `ch` into the slab ===============================
+        {
+            const int s = ch >= nblk0 ? 1 : 0;
+            const int bi = ch - (s ? nblk0 : 0);
+            const int lv = A.seg[s].log2Lin - 2, vpr = 1 << lv;
+            const int Lin = A.seg[s].Lin;
+            const int blk = A.seg[s].blk, blkp = A.seg[s].blkp;
+            const int c = tid, cg = bi * blk + c;
+            const bool cok = c < blk;
+            const int pad = A.seg[s].taps == 3 ? 1 : 0;
+            const int ups = A.seg[s].ups, act = A.seg[s].act;
+            if (A.seg[s].gn) {
+                const int gs = A.seg[s].gs;
+                const float ga = cok ? A.seg[s].gamma[cg] : 0.f, be = cok ? A.seg[s].beta[cg] : 0.f;
+                // per-float4 (mean, M2); equal-size pieces combine exactly (Chan et al.)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float mv = ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) * 0.25f;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float d = v[j][q] - mv; m2 += d * d; }
+                    ex_mean[j * 256 + c] = mv;
+                    ex_m2[j * 256 + c] = m2;
+                }
+                lds_bar();
+                const int ng = blk / gs, nq = nb * ng;
+                const float inv_n = 1.f / (float)(gs * vpr), inv_cnt = 1.f / (float)(gs * Lin);
+                for (int q0 = 0; q0 < nq; q0 += 32) {
+                    const int q = q0 + (tid >> 3), lt = tid & 7;
+                    const bool qok = q < nq;
+                    const int i = qok ? q / ng : 0;
+                    const int g = qok ? q - i * ng : 0;
+                    const float *pm = ex_mean + (i * vpr) * 256 + g * gs;
+                    const float *p2 = ex_m2 + (i * vpr) * 256 + g * gs;
+                    float sm = 0.f;
+                    if (qok)
+                        for (int jj = 0; jj < vpr; ++jj)
+                            for (int k = lt; k < gs; k += 8) sm += pm[jj * 256 + k];
+                    sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 1);
+                    const float gm = sm * inv_n;
+                    float m2 = 0.f;
+                    if (qok)
+                        for (int jj = 0; jj < vpr; ++jj)
+                            for (int k = lt; k < gs; k += 8) { const float d = pm[jj * 256 + k] - gm; m2 += p2[jj * 256 + k] + 4.f * (d * d); }
+                    m2 += __shfl_xor(m2, 4); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 1);
+                    if (qok && lt == 0) { gstat[2 * q] = gm; gstat[2 * q + 1] = 1.f / sqrtf(m2 * inv_cnt + 1e-5f); }
+                }
+                lds_bar();
+                if (cok) {
+                    const int gq = c / gs;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const int i = j >> lv;
+                        const int q = (i < nb) ? i * ng + gq : 0;
+                        const float gm = gstat[2 * q], gsc = ga * gstat[2 * q + 1];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float w = (v[j][k] - gm) * gsc + be;
+                            if (act) w = silu2(w);
+                            v[j][k] = w;
+                        }
+                    }
+                }
+            } else if (act) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[j][k] = silu2(v[j][k]);
+            }
+            // ---- split and write the slab [batch row][position][channel]; zero halo positions and padded channels ----
+            if (c < blkp) {
+                const int Lcov = ups ? 2 * Lin : Lin;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int i = j >> lv, jj = j & (vpr - 1);
+                    if (i < nb) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float w0 = v[j][k];
+                            saturated |= fabsf(w0) > 65504.f;
+                            const float w = __builtin_amdgcn_fmed3f(w0, -65504.f, 65504.f);
+                            const _Float16 h = (_Float16)w;
+                            const _Float16 lo = (_Float16)(w - (float)h);
+                            const int l = 4 * jj + k;
+                            _Float16 *dst = slab + (i * A.Lsl + pad + (ups ? 2 * l : l)) * cs + c;
+                            dst[0] = h; dst[plane] = lo;
+                            if (ups) { dst[cs] = h; dst[cs + plane] = lo; }
+                        }
+                    }
+                }
+                for (int i = 0; i < nb; ++i) {
+                    _Float16 *row0 = slab + (i * A.Lsl) * cs + c;
+                    for (int p = 0; p < pad; ++p) { row0[p * cs] = (_Float16)0.f; row0[p * cs + plane] = (_Float16)0.f; }
+                    for (int p = pad + Lcov; p < A.Lsl; ++p) { row0[p * cs] = (_Float16)0.f; row0[p * cs + plane] = (_Float16)0.f; }
+                }
+            }
+            lds_bar();
+        }
+        // =========================== MFMAs of this K block ============================================
+        const int chn = ch + A.KS;
+        const bool has_next = chn < nch;
+        const WS nxt = has_next ? make_ws(chn) : cur;
+        f32x4 vn[PREF ? VEC : 1];
+        if constexpr (PREF) { if (has_next) issue_operand(chn, vn); }
+        {
+            const int s = ch >= nblk0 ? 1 : 0;
+            const int lbase = (colb * A.Lsl + coll * A.seg[s].stride) * cs + 8 * (lane >> 5);
+            const int nk = cur.nk;
+            auto compute = [&](const f16x8 (&a)[C2_U][2], int g) {
+#pragma unroll
+                for (int u = 0; u < C2_U; ++u) {
+                    const int it = cur.it_beg + g * C2_U + u;
+                    if (it < cur.it_end) {
+                        const int tap = (it >= nk) + (it >= 2 * nk);
+                        const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
+                        const f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
+                        const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + plane);
+                        acc_lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_lh, 0, 0, 0);
+                        acc_hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_hl, 0, 0, 0);
+                        acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
+                    }
+                }
+            };
+            const int P = max(C2_D, ((cur.ngroups + C2_D - 1) / C2_D) * C2_D);
+#pragma unroll 1
+            for (int g0 = 0; g0 < P; g0 += C2_D) {
+#pragma unroll
+                for (int d = 0; d < C2_D; ++d) {
+                    const int g = g0 + d;
+                    if (g < cur.ngroups) compute(ring[d], g);
+                    const int vg = g + C2_D;
+                    if (vg < cur.ngroups) load_group(ring[d], cur, vg);
+                    else if (has_next && vg >= P && vg - P < nxt.ngroups) load_group(ring[d], nxt, vg - P);
+                }
+            }
+        }
+        if (!has_next) break;
+        lds_bar();                   // every wave is done reading the slab
+        ch = chn;
+        cur = nxt;
+        if constexpr (PREF) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] = vn[j];
+        } else {
+            issue_operand(ch, v);
+        }
+    }
+    if (saturated) atomicAdd(A.sat, 1u);
+
+    // ---- sum the three product streams, then the k-parts of the workgroup (LDS) ------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (acc_lh[r] + acc_hl[r]) + acc_hh[r];
+    lds_bar();
+    if (kpart > 0) {
+        float *dst = red + ((kpart - 1) * nct + ct) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+    }
+    lds_bar();
+    if (kpart == 0) {
+        for (int kp = 1; kp < KP; ++kp) {
+            const float *srcp = red + ((kp - 1) * nct + ct) * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += srcp[r * 64 + lane];
+        }
+    }
+    // ---- cross-workgroup K reduction (hand-off recipe R1, cdna_hip_programming.md §6 G16): write-through
+    //      partial tiles -> vmcnt(0) -> barrier -> relaxed ticket; the last arriver acquires and sums in slice order
+    if (A.KS > 1) {
+        const size_t slot = (size_t)by * A.ntiles + tile;
+        float *mine = A.part + (((size_t)kz * A.nby + by) * A.ntiles + tile) * A.part_stride;
+        if (kpart == 0) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 val = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+                float *dst = mine + ((size_t)(ct * 4 + r4) * 64 + lane) * 4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(val) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *flag = reinterpret_cast<int *>(red + 3 * 1024);
+        if (tid == 0) {
+            const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (prev == A.KS - 1) ? 1 : 0;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(A.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        if (kpart == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int z = 0; z < A.KS; ++z) {
+                const float *src = A.part + (((size_t)z * A.nby + by) * A.ntiles + tile) * A.part_stride;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4 *>(src + ((size_t)(ct * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[4 * r4 + q] += pv[q];
+                }
+            }
+        }
+    }
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    if (kpart == 0) {
+        const int m = ct * 32 + (lane & 31);
+        const bool mok = m < M;
+        const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = tile * 32 + frag_row(r, lane);
+            if (mok && co < A.Cout) A.out[b * A.out_bstride + (long)co * A.Lout + l] = acc[r] * inv_sc + pre_add[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation
+// ---------------------------------------------------------------------------------------------
+__global__ void c2_absmax_kernel(const float *src, size_t n, unsigned *out) {
+    unsigned m = 0u;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(src[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// sc = {SC, 1/SC, max|W| bits}: SC = 2^(8 - floor(log2 max|W|)), i.e. max |W| * SC in [256, 512)
+__global__ void c2_scale_kernel(float *sc) {
+    const unsigned b = __float_as_uint(sc[2]);
+    int e = (int)(b >> 23) - 127;
+    if (b == 0u || e > 100 || e < -100) e = 8;         // degenerate weights: SC = 1
+    sc[0] = __uint_as_float((unsigned)(127 + 8 - e) << 23);
+    sc[1] = __uint_as_float((unsigned)(127 - 8 + e) << 23);
+}
+
+struct PackSeg2 { int C, Cp8, taps, blk, blkp, k16_off, kg_off8; };
+
+// fp32 fragment-major pack of one layer (common.h) -> two fragment-major fp16 planes of SC * W in the K-block
+// order of the f16x2 kernel; padded channels are zero
+__global__ void c2_pack_kernel(const float *wp, int KGtot, int ntiles, PackSeg2 s0, PackSeg2 s1, int nseg, int KS16,
+                               const float *sc, _Float16 *dst) {
+    const float scale = sc[0];
+    const long total = (long)ntiles * KS16 * 512;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int el = e & 7, lane = (e >> 3) & 63;
+        const long tk = e >> 9;
+        const int ks = (int)(tk % KS16), tile = (int)(tk / KS16);
+        const PackSeg2 S = (nseg > 1 && ks >= s1.k16_off) ? s1 : s0;
+        const int nk = S.blkp >> 4;
+        const int local = ks - S.k16_off, per_blk = S.taps * nk;
+        const int bi = local / per_blk, r = local - bi * per_blk;
+        const int tap = r / nk, kk = r - tap * nk;
+        const int cb = kk * 16 + 8 * (lane >> 5) + el, c = bi * S.blk + cb;
+        float x = 0.f;
+        if (cb < S.blk && c < S.C) {
+            const int kg = S.kg_off8 + tap * (S.Cp8 >> 3) + (c >> 3);
+            x = wp[((size_t)((size_t)tile * KGtot + kg) * 64 + (lane & 31) + 32 * ((c >> 2) & 1)) * 4 + (c & 3)] * scale;
+        }
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const size_t base = ((size_t)tile * KS16 + ks) * 1024 + (size_t)lane * 8 + el;
+        dst[base] = h; dst[base + 512] = l;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// K blocking of one segment: a block is what one workgroup stages at a time (thread <-> channel, <= 256),
+// holds whole GroupNorm groups and is padded to a multiple of 16 channels in the packed K axis.
+static bool seg_blocking(const SegPlan &sp, int &blk, int &blkp, int &nblk) {
+    const int C = sp.C;
+    if (sp.gn) {
+        if (C % 32) return false;
+        const int gs = C / 32;
+        const int unit = gs * 8 / gcd_i(gs, 8);           // lcm(gs, 8)
+        if (unit > 256 || C % unit) return false;
+        int m = 1;
+        while (unit * m * 2 <= 256 && (C / unit) % (m * 2) == 0) m *= 2;
+        blk = unit * m;
+    } else {
+        blk = 0;
+        for (int b = std::min(256, C); b >= 1; --b)
+            if (C % b == 0 && (b % 16 == 0 || b == C)) { blk = b; break; }
+        if (!blk) return false;
+        if (blk < 64 && C > 256) return false;             // awkward channel counts: leave to the fp32 kernel
+    }
+    blkp = ceil_div(blk, 16) * 16;
+    nblk = C / blk;
+    return true;
+}
+
+int conv2_plan_layout(surfd_unet *u) {
+    size_t off = 0;
+    int nsc = 0, id = 0;
+    for (auto &op : u->ops) {
+        if (op.kind != 0) continue;
+        ConvPlan &c = op.conv;
+        c.id = id++;
+        c.f16_ok = 1;
+        int k16 = 0;
+        for (int s = 0; s < c.nseg; ++s) {
+            if (!seg_blocking(c.seg[s], c.blk[s], c.blkp[s], c.nblk[s])) { c.f16_ok = 0; break; }
+            c.k16_off[s] = k16;
+            k16 += c.nblk[s] * c.seg[s].taps * (c.blkp[s] / 16);
+        }
+        if (!c.f16_ok) continue;
+        c.KS16 = k16;
+        c.whf_off = off;
+        off += (size_t)ceil_div(c.Cout, 32) * k16 * 1024;
+        c.sc_idx = nsc++;
+    }
+    u->whf_halfs = off;
+    u->n_sc = nsc;
+    return SURFD_OK;
+}
+
+int conv2_finalize(surfd_unet *u, hipStream_t st) {
+    if (!u->whf_halfs) return SURFD_OK;
+    if (!u->whf) {
+        HIP_TRY(hipMalloc((void **)&u->whf, u->whf_halfs * sizeof(_Float16)));
+        HIP_TRY(hipMalloc((void **)&u->wsc, (size_t)u->n_sc * 4 * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&u->sat, sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(u->sat, 0, sizeof(unsigned), st));
+    }
+    HIP_TRY(hipMemsetAsync(u->wsc, 0, (size_t)u->n_sc * 4 * sizeof(float), st));
+    for (auto &op : u->ops) {
+        if (op.kind != 0 || !op.conv.f16_ok) continue;
+        const ConvPlan &c = op.conv;
+        const int ntiles = ceil_div(c.Cout, 32);
+        float *sc = u->wsc + (size_t)c.sc_idx * 4;
+        const size_t nfl = (size_t)ntiles * c.KGtot * 256;
+        hipLaunchKernelGGL(c2_absmax_kernel, dim3((unsigned)std::min<size_t>(ceil_div<size_t>(nfl, 1024), 512)), dim3(256), 0, st,
+                           (const float *)(u->wpack + c.w_off), nfl, reinterpret_cast<unsigned *>(sc + 2));
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(c2_scale_kernel, dim3(1), dim3(1), 0, st, sc);
+        LAUNCH_CHECK();
+        PackSeg2 ps[2];
+        memset(ps, 0, sizeof(ps));
+        for (int s = 0; s < c.nseg; ++s) {
+            ps[s].C = c.seg[s].C; ps[s].Cp8 = ceil_div(c.seg[s].C, 8) * 8; ps[s].taps = c.seg[s].taps;
+            ps[s].blk = c.blk[s]; ps[s].blkp = c.blkp[s]; ps[s].k16_off = c.k16_off[s]; ps[s].kg_off8 = c.kg_off[s];
+        }
+        const long total = (long)ntiles * c.KS16 * 512;
+        hipLaunchKernelGGL(c2_pack_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(total, 256), 4096)), dim3(256), 0, st,
+                           (const float *)(u->wpack + c.w_off), c.KGtot, ntiles, ps[0], ps[1], c.nseg, c.KS16,
+                           (const float *)sc, u->whf + c.whf_off);
+        LAUNCH_CHECK();
+    }
+    return SURFD_OK;
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunchIO &io, hipStream_t st) {
+    if (!c.f16_ok || !u->whf) return 1;
+    Conv2Args A;
+    memset(&A, 0, sizeof(A));
+    A.nseg = c.nseg; A.Cout = c.Cout; A.B = B;
+    A.Lout = c.ds_out ? L / c.ds_out : 1;
+    if (A.Lout < 1 || (A.Lout & (A.Lout - 1))) return 1;
+    while ((1 << A.log2Lout) < A.Lout) ++A.log2Lout;
+    auto resolve = [&](const View &v, int ds, bool is_out, float *&ptr, long &bs) {
+        const int len = ds ? L / ds : 1;
+        if (v.buf >= 0) {
+            ptr = u->buf_ptr[v.buf] + (long)v.choff * len;
+            bs = (long)u->bufs[v.buf].C * len;
+        } else if (is_out) { ptr = io.ext_out; bs = io.ext_out_bs; }
+        else { ptr = const_cast<float *>(io.ext_in); bs = io.ext_in_bs; }
+    };
+    int Lin0 = 0, max_lsl = 1, max_blkp = 16;
+    for (int s = 0; s < c.nseg; ++s) {
+        const SegPlan &sp = c.seg[s];
+        if (!sp.ds) return 1;                       // Linear layers of the embedding path stay on the fp32 kernel
+        Seg2 &S = A.seg[s];
+        float *p; long bs;
+        resolve(sp.src, sp.ds, false, p, bs);
+        S.x = p; S.bstride = bs;
+        S.C = sp.C; S.Lin = L / sp.ds;
+        if (S.Lin < 4 || S.Lin > 64 || (S.Lin & (S.Lin - 1))) return 1;
+        while ((1 << S.log2Lin) < S.Lin) ++S.log2Lin;
+        if (s == 0) Lin0 = S.Lin; else if (S.Lin != Lin0) return 1;
+        S.taps = sp.taps; S.stride = sp.stride; S.ups = sp.ups; S.gn = sp.gn; S.act = sp.act;
+        if (sp.gn) {
+            S.gamma = u->vecs + u->vec_off[sp.gnkey + ".weight"]; S.beta = u->vecs + u->vec_off[sp.gnkey + ".bias"];
+            S.gs = sp.C / 32;
+        }
+        S.blk = c.blk[s]; S.blkp = c.blkp[s]; S.nblk = c.nblk[s]; S.k16_off = c.k16_off[s];
+        const int lsl = sp.taps == 3 ? (sp.stride == 2 ? 2 * A.Lout + 1 : A.Lout + 2) : A.Lout;
+        max_lsl = std::max(max_lsl, lsl);
+        max_blkp = std::max(max_blkp, S.blkp);
+    }
+    A.Lsl = max_lsl;
+    const int VEC = Lin0 == 64 ? 16 : 8;
+    int nb = std::min({B, (VEC * 4) / Lin0, std::max(1, 64 / A.Lout), 8});
+    if (nb * A.Lout > 64) return 1;
+    A.bchunk = nb;
+    A.cs = max_blkp + 8;
+    const int rows = nb * A.Lsl;
+    A.plane = rows * A.cs;
+    size_t lds = (size_t)A.plane * 2 * sizeof(_Float16);
+    lds = (lds + 15) & ~(size_t)15;
+    A.off_ex = (int)lds;
+    lds += ((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float);
+    A.off_red = (int)lds;
+    lds += (3 * 1024 + 4) * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    A.whf = u->whf + c.whf_off; A.KS16 = c.KS16;
+    A.sc = u->wsc + (size_t)c.sc_idx * 4;
+    A.bias = u->vecs + c.bias_off;
+    if (c.emb_off >= 0 && io.emb) {
+        A.emb = io.emb + c.emb_off; A.emb_bstride = io.emb_bs; A.step_ptr = io.step_ptr; A.emb_step_stride = (long)B * io.emb_bs;
+    }
+    if (c.res.buf != -1) { float *p; long bs; resolve(c.res, c.ds_out, false, p, bs); A.res = p; A.res_bstride = bs; }
+    { float *p; long bs; resolve(c.dst, c.ds_out, true, p, bs); A.out = p; A.out_bstride = bs; }
+    A.ntiles = ceil_div(c.Cout, 32);
+    A.nby = ceil_div(B, nb);
+    // K slices over workgroups when (tiles x batch chunks) under-fills the chip: whole K blocks per slice
+    const int nch = c.nblk[0] + (c.nseg > 1 ? c.nblk[1] : 0);
+    static const int ks_fill = env_int("SURFD_CONV2_FILL", 256);       // workgroups aimed at
+    static const int ks_max = env_int("SURFD_CONV2_KSMAX", 16);
+    static const int ks_min_base = env_int("SURFD_CONV2_NOSPLIT_ABOVE", 160);
+    const int base = A.ntiles * A.nby;
+    int KS = 1;
+    if (base < ks_min_base && nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / base)});
+    A.part_stride = 2 * 1024;
+    if ((size_t)KS * base * A.part_stride > u->part_floats || base > 8192) KS = 1;
+    A.KS = KS;
+    A.part = u->part; A.counters = u->counters;
+    A.sat = u->sat;
+    const int G = A.ntiles * KS;
+    dim3 grid((unsigned)(8 * ceil_div(G, 8) * A.nby));
+    static const int pref = env_int("SURFD_CONV2_PREF", 1);
+    if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
+    else if (pref) hipLaunchKernelGGL((conv2_kernel<8, true>), grid, dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((conv2_kernel<8, false>), grid, dim3(256), lds, st, A);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+int conv2_set_attributes() {
+    const int max_lds = 160 * 1024;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    return SURFD_OK;
+}
+
+}  // namespace surfd

@@ -186,7 +186,9 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     float eta_bits_f = cfg->eta;
     long eta_bits = 0;
     memcpy(&eta_bits, &eta_bits_f, sizeof(float));
-    const long key[6] = {1, B, L, cfg->sampler, cfg->clip_denoised, eta_bits};
+    // the workspace generation covers every buffer whose address the graph bakes in (activation arena, embedding
+    // table, precision-dependent kernel choice): a reallocation anywhere re-captures instead of replaying stale pointers
+    const long key[6] = {unet_workspace_generation(u), B, L, cfg->sampler, cfg->clip_denoised, eta_bits};
     if (memcmp(key, ls->key, sizeof(key)) != 0) {
         if (ls->exec) { (void)hipGraphExecDestroy(ls->exec); ls->exec = nullptr; }
         if (ls->graph) { (void)hipGraphDestroy(ls->graph); ls->graph = nullptr; }

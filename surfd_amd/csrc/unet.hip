@@ -22,6 +22,7 @@
 // common.h (k order inside a segment: tap-major, channel-minor, channels padded to 8).
 #include "common.h"
 #include "unet_api.h"
+#include "unet_plan.h"
 #include <string.h>
 #include <algorithm>
 #include <stdlib.h>
@@ -623,71 +624,6 @@ using namespace surfd;
 
 namespace {
 
-struct ParamInfo {
-    std::string key;
-    std::vector<int64_t> shape;
-    bool is_set = false;
-};
-
-struct View { int buf = -1; int choff = 0; };   // buf: index into buffers, -2 = external input, -3 = external output
-
-struct BufInfo { int C; int ds; };               // [B][C][L/ds]
-
-struct SegPlan {
-    View src;
-    int C = 0, taps = 1, stride = 1, ups = 0, gn = 0, act = 0;
-    std::string wkey;      // weight tensor packed into this segment
-    std::string gnkey;     // "<prefix>" of GroupNorm weight/bias
-    int ds = 1;            // source ds (ds == 0: length-1 "linear" operand)
-};
-
-struct ConvPlan {
-    SegPlan seg[2];
-    int nseg = 1;
-    int Cout = 0;
-    int ds_out = 1;
-    std::vector<std::string> bias_keys;   // summed
-    int emb_off = -1;
-    View res, dst;
-    // resolved at finalize
-    size_t w_off = 0; int KGtot = 0; int kg_off[2] = {0, 0}; size_t bias_off = 0; int gn_off[2] = {-1, -1};
-};
-
-struct AttnPlan { View qkv, out; int C = 0, ds = 1; };
-
-struct Op { int kind; ConvPlan conv; AttnPlan attn; };   // 0 conv, 1 attn
-
-}  // namespace
-
-struct surfd_unet {
-    surfd_unet_cfg cfg;
-    int ted = 0;                                  // time-embed dim
-    std::vector<ParamInfo> params;
-    std::map<std::string, int> pindex;
-    std::vector<BufInfo> bufs;
-    std::vector<Op> ops;                          // denoiser body, in execution order
-    ConvPlan lin1, lin2, lin3;                    // embedding path
-    int emb_total = 0;                            // sum of ResBlock Cout (14112)
-    std::vector<std::pair<std::string, int>> emb_layers;   // (prefix, Cout) in table order
-    // device state
-    bool allocated = false, finalized = false;
-    int device = -1;
-    float *wpack = nullptr; size_t wpack_floats = 0;
-    float *vecs = nullptr; size_t vec_floats = 0;
-    std::map<std::string, size_t> vec_off;        // raw vectors (GN gamma/beta, biases) by key
-    float *label_table = nullptr;
-    // workspace (grow-only)
-    std::vector<float *> buf_ptr; int ws_B = 0, ws_L = 0;
-    float *temb = nullptr, *h1 = nullptr, *emb = nullptr, *emb_table = nullptr; int emb_rows_cap = 0; int emb_rows = 0, emb_B = 0;
-    int64_t *t_dev = nullptr; int t_cap = 0;
-    float *part = nullptr; size_t part_floats = 0;     // split-K partial tiles
-    long long *dbg = nullptr; int dbg_launch = 0;      // SURFD_CONV_DEBUG=1: per-launch phase stamps
-    surfd::LoopState loop;
-    int *counters = nullptr;
-};
-
-namespace {
-
 void add_param(surfd_unet *u, const std::string &k, std::vector<int64_t> shape) {
     u->pindex[k] = (int)u->params.size();
     u->params.push_back({k, std::move(shape)});
@@ -948,6 +884,9 @@ int unet_alloc(surfd_unet *u) {
     for (auto &op : u->ops) if (op.kind == 0) place(op.conv);
     place(u->lin1); place(u->lin2); place(u->lin3);
     u->wpack_floats = off;
+    { int rc2 = conv2_plan_layout(u); if (rc2) return rc2; }
+    { int rc2 = conv2_set_attributes(); if (rc2) return rc2; }
+    if (const char *pe = getenv("SURFD_UNET_PRECISION")) u->precision = !strcmp(pe, "fp32") ? 0 : 1;
     HIP_TRY(hipMalloc((void **)&u->wpack, off * sizeof(float)));
     HIP_TRY(hipMemset(u->wpack, 0, off * sizeof(float)));
     // ---- vectors: every 1-D parameter raw, then combined biases ----
@@ -1029,6 +968,7 @@ void surfd_unet_destroy(surfd_unet *u) {
     if (u->t_dev) (void)hipFree(u->t_dev);
     if (u->part) (void)hipFree(u->part);
     if (u->counters) (void)hipFree(u->counters);
+    for (void *p : {(void *)u->whf, (void *)u->wsc, (void *)u->sat}) if (p) (void)hipFree(p);
     if (u->loop.exec) (void)hipGraphExecDestroy(u->loop.exec);
     if (u->loop.graph) (void)hipGraphDestroy(u->loop.graph);
     if (u->loop.cap_stream) (void)hipStreamDestroy(u->loop.cap_stream);
@@ -1116,7 +1056,9 @@ int surfd_unet_finalize(surfd_unet *u, surfd_stream s) {
                                (size_t)el.second * sizeof(float), hipMemcpyDeviceToDevice, st));
         row += el.second;
     }
+    if ((rc = conv2_finalize(u, st))) return rc;
     u->finalized = true;
+    u->ws_gen++;
     return SURFD_OK;
 }
 
@@ -1137,6 +1079,7 @@ int ensure_workspace(surfd_unet *u, int B, int L) {
         HIP_TRY(hipMalloc((void **)&u->buf_ptr[i], n * sizeof(float)));
     }
     u->ws_B = nB; u->ws_L = nL;
+    u->ws_gen++;                 // pointers baked into a cached loop graph are stale now
     return SURFD_OK;
 }
 
@@ -1146,6 +1089,11 @@ struct Resolved { float *ptr; long bstride; };
 int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext_in[2], const long ext_in_bs[2],
                 const int ext_bmod[2], float *ext_out, long ext_out_bs, const float *emb, long emb_bs, hipStream_t st,
                 const int *step_ptr = nullptr) {
+    if (u->precision == 1 && c.f16_ok && (u->dbg_only < 0 || u->dbg_only == c.id)) {
+        const ConvLaunchIO io{ext_in[0], ext_in_bs[0], ext_out, ext_out_bs, emb, emb_bs, step_ptr};
+        const int r2 = launch_conv2(u, c, B, L, io, st);
+        if (r2 <= 0) return r2;          // launched (0) or failed (< 0); 1 = shape not covered -> fp32 kernel below
+    }
     ConvArgs A;
     memset(&A, 0, sizeof(A));
     A.nseg = c.nseg; A.Cout = c.Cout; A.B = B;
@@ -1303,6 +1251,7 @@ int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, c
         HIP_TRY(hipMalloc((void **)&u->emb, (size_t)rows * u->ted * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&u->emb_table, (size_t)rows * u->emb_total * sizeof(float)));
         u->emb_rows_cap = rows;
+        u->ws_gen++;
     }
     const int mc = u->cfg.model_channels;
     hipLaunchKernelGGL(temb_kernel, dim3(std::min(ceil_div(rows * mc / 2, 256), 1024)), dim3(256), 0, st, t_dev, rows, mc, u->temb);
@@ -1357,6 +1306,7 @@ int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows,
 }
 
 LoopState *unet_loop_state(surfd_unet *u) { return &u->loop; }
+long unet_workspace_generation(surfd_unet *u) { return u->ws_gen; }
 
 int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st,
                           const int *step_ptr) {
@@ -1396,6 +1346,32 @@ extern "C" int surfd_unet_debug_read(surfd_unet *u, long long *out, int max_laun
     if (hipMemcpy(out, u->dbg, (size_t)n * 16 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     u->dbg_launch = 0;
     return n;
+}
+
+extern "C" int surfd_unet_set_precision(surfd_unet *u, int mode) {
+    if (!u || (mode != 0 && mode != 1)) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_precision: mode must be 0 (fp32) or 1 (f16x2)");
+    if (u->precision != mode) { u->precision = mode; u->ws_gen++; }
+    return SURFD_OK;
+}
+
+// developer aid: op >= 0 restricts the f16x2 kernel to that one conv op (all others run exact fp32), -1 lifts it
+extern "C" int surfd_unet_debug_only_op(surfd_unet *u, int op) {
+    if (!u) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_debug_only_op: null handle");
+    u->dbg_only = op; u->ws_gen++;
+    return SURFD_OK;
+}
+
+extern "C" int surfd_unet_saturation_count(surfd_unet *u, int reset, int64_t *count, surfd_stream s) {
+    if (!u || !count) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_saturation_count: null argument");
+    *count = 0;
+    if (!u->sat) return SURFD_OK;
+    unsigned v = 0;
+    hipStream_t st = as_stream(s);
+    HIP_TRY(hipMemcpyAsync(&v, u->sat, sizeof(v), hipMemcpyDeviceToHost, st));
+    if (reset) HIP_TRY(hipMemsetAsync(u->sat, 0, sizeof(v), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *count = v;
+    return SURFD_OK;
 }
 
 extern "C" int surfd_unet_forward(surfd_unet *u, const float *x, const int64_t *t, const float *ctx, const int64_t *cls,

@@ -28,4 +28,6 @@ struct LoopState {
     long key[6] = {0, 0, 0, 0, 0, 0};
 };
 LoopState *unet_loop_state(surfd_unet *u);
+// changes whenever a device buffer that a captured loop graph refers to is reallocated (or the kernel choice changes)
+long unet_workspace_generation(surfd_unet *u);
 }  // namespace surfd

@@ -95,6 +95,20 @@ class MDM(nn.Module):
             self._bound_key = key
         return L, self._handle
 
+    def set_precision(self, mode: str) -> None:
+        """'f16x2' (default: split-fp16 products on the fp16 matrix pipe, fp32 accumulation, operands clamped to the
+        fp16 range and counted) or 'fp32' (exact fp32 MFMA) for the denoiser's convolutions."""
+        L, h = self._native()
+        N.check(L.surfd_unet_set_precision(h, {"fp32": 0, "f16x2": 1}[mode]))
+
+    def saturation_count(self, reset: bool = True) -> int:
+        """Workgroups of the f16x2 conv kernel that clamped an operand to +-65504 since the last reset; a non-zero
+        value means this checkpoint leaves the range the mode is exact for -> use set_precision('fp32')."""
+        L, h = self._native()
+        n = C.c_int64()
+        N.check(L.surfd_unet_saturation_count(h, int(reset), C.byref(n), N.stream()))
+        return int(n.value)
+
     # ---- conditioning dispatch (mdm.py:91-110) -----------------------------------------------------------
     def conditioning(self, y: Optional[dict], B: int):
         """-> (context[B,512] | None, labels[B] int64 | None) as contiguous device tensors."""
