@@ -52,16 +52,37 @@ def parse():
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--decoder-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="forward decoder kernel arithmetic (include/surfd_hip.h: surfd_decoder_set_precision)")
-    ap.add_argument("--decoder-blocks", type=int, default=128,
+    ap.add_argument("--decoder-blocks", type=int, default=160,
                     help="with --pipeline 1: persistent decoder workgroups per launch while the next batch's reverse loop "
                          "runs on the remaining CUs (the last batch's grids, with nothing left to overlap, use every CU)")
     ap.add_argument("--pipeline", type=int, default=1,
-                    help="1: overlap the reverse loop of batch s+1 with the grid evaluation of batch s on two HIP streams")
+                    help="1: overlap the reverse loops of the next batches with the grid evaluation of the current one")
+    ap.add_argument("--loop-chains", type=int, default=2,
+                    help="with --pipeline 1: reverse loops (of different batches) in flight at once, each on its own stream "
+                         "and execution context (MDM.replica)")
+    ap.add_argument("--unet-precision", choices=["f16x2", "fp32"], default="f16x2",
+                    help="denoiser conv arithmetic (include/surfd_hip.h: surfd_unet_set_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def setup_dist(n_gpus):
+    if n_gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(n_gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,7 +102,7 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-def build_models(latent, precision):
+def build_models(latent, precision, unet_precision="f16x2"):
     from surfd_amd import synth
     from surfd_amd.cbndec import CbnDecoder
     from surfd_amd.mdm import create_model_and_diffusion, load_model_wo_clip
@@ -92,6 +113,7 @@ def build_models(latent, precision):
     load_model_wo_clip(model, synth.synth_unet_state_dict())
     model.to("cuda")
     model.eval()
+    model.set_precision(unet_precision)
     dec = CbnDecoder(63, latent, 512, 5)
     dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig(latent_dim=latent)), strict=True)
     dec = dec.cuda().eval()
@@ -145,7 +167,7 @@ def main():
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
     L = Nn.lib()
-    model, diffusion, dec = build_models(a.latent, a.decoder_precision)
+    model, diffusion, dec = build_models(a.latent, a.decoder_precision, a.unet_precision)
     if a.diffusion_steps != 1000:
         from surfd_amd.diffusion import create_gaussian_diffusion
         diffusion = create_gaussian_diffusion(types.SimpleNamespace(noise_schedule="cosine", sigma_small=True),
@@ -158,8 +180,12 @@ def main():
     grads = [torch.empty(N, N, N, 3, device="cuda") for _ in range(B)]
     stats = []
 
-    def sample_latents():
-        return diffusion.p_sample_loop(model, (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}},
+    chains = [model] + [model.replica() for _ in range(max(1, a.loop_chains) - 1)] if a.pipeline else [model]
+    for m in chains[1:]:
+        m.set_precision(a.unet_precision)
+
+    def sample_latents(chain=0):
+        return diffusion.p_sample_loop(chains[chain], (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}},
                                        noise_stream=noise, fused=True)
 
     def fill_grids(lat, collect=False):
@@ -176,7 +202,8 @@ def main():
         return lat
 
     from surfd_amd.parallel import BatchPipeline
-    pipe = BatchPipeline(dec, lambda s: sample_latents(), lambda s, lat: fill_grids(lat), a.decoder_blocks)
+    pipe = BatchPipeline(dec, lambda s, q: sample_latents(q), lambda s, lat: fill_grids(lat), a.decoder_blocks,
+                         loop_chains=len(chains))
 
     def run_steps(k_steps):
         """k_steps full passes (every batch: reverse loop + 8 grids), start to finish.  Pipelined mode

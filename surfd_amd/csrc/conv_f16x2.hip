@@ -52,8 +52,9 @@ struct Conv2Args {
     const float *bias;     // [Cout]
     const float *emb;      // emb[b * emb_bstride + co] or null
     long emb_bstride;
-    const float *res;      // res[b * res_bstride + co * Lout + l] or null
+    const float *res;      // res[b * res_bstride + co * res_cstride + l * res_lstride]
     long res_bstride;
+    int res_cstride, res_lstride, has_res, has_emb;   // unused emb / res point at the bias vector with zero strides
     float *out;
     long out_bstride;
     int Cout, Lout, log2Lout, B;
@@ -67,10 +68,11 @@ struct Conv2Args {
     const int *step_ptr;   // device loop counter (embedding rows advance by emb_step_stride per step) or null
     long emb_step_stride;
     unsigned *sat;         // saturation counter
+    long long *dbg;        // -DSURFD_C2_STAMPS builds: 16 phase stamps (100 MHz ticks) of workgroup 0
 };
 
 constexpr int C2_U = 4;    // k16 steps per ring stage
-constexpr int C2_D = 3;    // ring stages (24 x 1 KB fragments in flight per wave)
+constexpr int C2_D = 2;    // ring stages (16 x 1 KB fragments in flight per wave); 3 does not fit 256 VGPRs (2 workgroups per CU)
 
 __device__ __forceinline__ float silu2(float v) { return v * __frcp_rn(1.f + __expf(-v)); }
 
@@ -83,7 +85,7 @@ __device__ __forceinline__ void lds_bar() {
 // VEC: float4 registers a thread holds while staging its channel (8: operand rows of 4..32 positions,
 // nb * Lin <= 32; 16: 64 positions).  PREF: request the next K block's operand before the current MFMAs.
 template <int VEC, bool PREF>
-__global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
+__global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args A) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
     float *ex_mean = reinterpret_cast<float *>(lds_raw + A.off_ex);     // [VEC][256]
@@ -92,6 +94,20 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
     float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SURFD_C2_STAMPS
+    long long stamp_[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) stamp_[i] = 0;
+#define C2_STAMP(i) do { stamp_[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define C2_STAMP_FIRST(i) do { if (ch == kz) C2_STAMP(i); } while (0)
+#else
+#define C2_STAMP(i) do { } while (0)
+#define C2_STAMP_FIRST(i) do { } while (0)
+#endif
+    C2_STAMP(0);
+#ifdef SURFD_C2_STAMPS
+    const long long cyc0_ = (long long)__builtin_readcyclecounter();
+#endif
     // ---- XCD-aware decode: group g = (tile, K slice); every batch chunk of a group on XCD g % 8 ----
     int tile, by, kz;
     {
@@ -129,6 +145,9 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
     for (int r = 0; r < 16; ++r) { acc_hh[r] = 0.f; acc_hl[r] = 0.f; acc_lh[r] = 0.f; }
 
     // ---- weight stream state of one K block for this wave ------------------------------------------
+    // Every wave of the workgroup runs the SAME static schedule (ngroups is wave-uniform; a wave whose k-part is
+    // shorter re-loads its last fragment and skips the MFMAs): all weight loads are unconditional, so the
+    // compiler's s_waitcnt bookkeeping stays exact and a ring stage is awaited with vmcnt(16), not vmcnt(0).
     struct WS { const _Float16 *base; int it_beg, it_end, ngroups, nk; };
     auto make_ws = [&](int ch) -> WS {
         const int s = ch >= nblk0 ? 1 : 0;
@@ -138,71 +157,77 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
         const int per = (iters + KP - 1) >> log2kp;
         WS w;
         w.nk = nk;
-        w.it_beg = kpart * per;
+        w.it_beg = min(kpart * per, iters);
         w.it_end = min(iters, w.it_beg + per);
-        const int n = max(w.it_end - w.it_beg, 0);
-        w.ngroups = (n + C2_U - 1) / C2_U;
+        w.ngroups = (per + C2_U - 1) / C2_U;
         w.base = A.whf + ((size_t)tile * A.KS16 + A.seg[s].k16_off + (size_t)bi * iters) * 1024 + lane * 8;
         return w;
     };
     f16x8 ring[C2_D][C2_U][2];
-    auto load_group = [&](f16x8 (&dst)[C2_U][2], const WS &w, int g) {
+    // fragments [it0, it0 + U) of K block w, clamped into the block (valid addresses even for an empty k-part)
+    auto load_group = [&](f16x8 (&dst)[C2_U][2], const _Float16 *base, int it0, int it_last) {
 #pragma unroll
         for (int u = 0; u < C2_U; ++u) {
-            const int it = min(w.it_beg + g * C2_U + u, w.it_end - 1);
-            const gf16x8 *p = (const gf16x8 *)(w.base + (size_t)it * 1024);
+            const int it = max(min(it0 + u, it_last), 0);
+            const gf16x8 *p = (const gf16x8 *)(base + (size_t)it * 1024);
             dst[u][0] = p[0];
             dst[u][1] = p[64];          // low plane: +512 halfs
         }
     };
 
     // ---- raw operand of one K block: thread <-> channel, VEC float4 covering (batch row, position) ----
-    auto issue_operand = [&](int ch, f32x4 (&v)[VEC]) {
+    // All global loads of this kernel are UNCONDITIONAL (addresses clamped into the tensor, validity applied to
+    // the value later): a load under a lane- or wave-dependent branch makes the compiler's vmcnt bookkeeping
+    // conservative, and one resulting s_waitcnt vmcnt(0) in front of the MFMAs serialises the whole weight ring.
+    auto issue_operand = [&](int ch, f32x4 (&v)[VEC], float &ga, float &be) {
         const int s = ch >= nblk0 ? 1 : 0;
         const int bi = ch - (s ? nblk0 : 0);
         const int lv = A.seg[s].log2Lin - 2;          // log2(float4 per row)
         const int Lin = A.seg[s].Lin;
-        const int cg = bi * A.seg[s].blk + tid;
-        const bool cok = tid < A.seg[s].blk;
+        const int cg = min(bi * A.seg[s].blk + tid, A.seg[s].C - 1);
         const float *src = A.seg[s].x + (long)cg * Lin;
         const long bstride = A.seg[s].bstride;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const int i = j >> lv, jj = j & ((1 << lv) - 1);
-            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (cok && i < nb) v[j] = *reinterpret_cast<const f32x4 *>(src + (b0 + i) * bstride + 4 * jj);
+            const int i = min(j >> lv, nb - 1), jj = j & ((1 << lv) - 1);
+            v[j] = *reinterpret_cast<const f32x4 *>(src + (b0 + i) * bstride + 4 * jj);
         }
+        ga = A.seg[s].gamma[cg]; be = A.seg[s].beta[cg];      // segments without GroupNorm point these at the bias vector
     };
 
     int ch = kz;
     WS cur = make_ws(ch);
     f32x4 v[VEC];
-    issue_operand(ch, v);
+    float ga, be;
+    issue_operand(ch, v, ga, be);
 #pragma unroll
-    for (int d = 0; d < C2_D; ++d)
-        if (d < cur.ngroups) load_group(ring[d], cur, d);
+    for (int d = 0; d < C2_D; ++d) load_group(ring[d], cur.base, cur.it_beg + d * C2_U, cur.it_end - 1);
 
     // ---- epilogue operands (bias + per-(step, sample) embedding + residual), requested now, used at the end ----
-    float pre_add[16];
+    // kept as three separate register sets and only combined in the epilogue: combining them here would put a
+    // wait for the (HBM-resident) embedding rows in front of the first K block
+    f32x4 pre_b[4], pre_e[4];
+    float pre_r[16];
     {
-        const float *embp = A.emb;
-        if (embp && A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
-        const int m = ct * 32 + (lane & 31);
-        const bool mok = kpart == 0 && m < M;
+        const float *embp = A.emb;                    // never null: the host points unused operands at the bias vector
+        if (A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
+        const int m = min(ct * 32 + (lane & 31), M - 1);
         const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
+        const int cmax4 = ((A.Cout + 3) & ~3) - 4;     // last aligned float4 of the (4-padded) per-channel vectors
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = tile * 32 + frag_row(r, lane);
-            float t = 0.f;
-            if (mok && co < A.Cout) {
-                t = A.bias[co];
-                if (embp) t += embp[b * A.emb_bstride + co];
-                if (A.res) t += A.res[b * A.res_bstride + (long)co * A.Lout + l];
+        for (int q = 0; q < 4; ++q) {
+            const int cob = min(tile * 32 + 8 * q + 4 * (lane >> 5), cmax4);      // rows frag_row(4q .. 4q+3, lane)
+            pre_b[q] = *reinterpret_cast<const f32x4 *>(A.bias + cob);
+            pre_e[q] = *reinterpret_cast<const f32x4 *>(embp + b * A.emb_bstride + cob);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = min(cob + k, A.Cout - 1);
+                pre_r[4 * q + k] = A.res[b * A.res_bstride + (long)co * A.res_cstride + l * A.res_lstride];
             }
-            pre_add[r] = t;
         }
     }
     bool saturated = false;
+    C2_STAMP(1);
 
     while (true) {
         // =========================== stage K block `ch` into the slab ===============================
@@ -218,7 +243,6 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
             const int ups = A.seg[s].ups, act = A.seg[s].act;
             if (A.seg[s].gn) {
                 const int gs = A.seg[s].gs;
-                const float ga = cok ? A.seg[s].gamma[cg] : 0.f, be = cok ? A.seg[s].beta[cg] : 0.f;
                 // per-float4 (mean, M2); equal-size pieces combine exactly (Chan et al.)
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -230,6 +254,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
                     ex_m2[j * 256 + c] = m2;
                 }
                 lds_bar();
+                C2_STAMP_FIRST(2);
                 const int ng = blk / gs, nq = nb * ng;
                 const float inv_n = 1.f / (float)(gs * vpr), inv_cnt = 1.f / (float)(gs * Lin);
                 for (int q0 = 0; q0 < nq; q0 += 32) {
@@ -253,6 +278,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
                     if (qok && lt == 0) { gstat[2 * q] = gm; gstat[2 * q + 1] = 1.f / sqrtf(m2 * inv_cnt + 1e-5f); }
                 }
                 lds_bar();
+                C2_STAMP_FIRST(3);
                 if (cok) {
                     const int gq = c / gs;
 #pragma unroll
@@ -283,7 +309,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
                     if (i < nb) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float w0 = v[j][k];
+                            const float w0 = cok ? v[j][k] : 0.f;
                             saturated |= fabsf(w0) > 65504.f;
                             const float w = __builtin_amdgcn_fmed3f(w0, -65504.f, 65504.f);
                             const _Float16 h = (_Float16)w;
@@ -302,13 +328,15 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
                 }
             }
             lds_bar();
+            C2_STAMP_FIRST(4);
         }
         // =========================== MFMAs of this K block ============================================
         const int chn = ch + A.KS;
         const bool has_next = chn < nch;
         const WS nxt = has_next ? make_ws(chn) : cur;
         f32x4 vn[PREF ? VEC : 1];
-        if constexpr (PREF) { if (has_next) issue_operand(chn, vn); }
+        float gan = 0.f, ben = 0.f;
+        if constexpr (PREF) issue_operand(has_next ? chn : ch, vn, gan, ben);      // unconditional (re-reads this block at the end)
         {
             const int s = ch >= nblk0 ? 1 : 0;
             const int lbase = (colb * A.Lsl + coll * A.seg[s].stride) * cs + 8 * (lane >> 5);
@@ -316,31 +344,42 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
             auto compute = [&](const f16x8 (&a)[C2_U][2], int g) {
 #pragma unroll
                 for (int u = 0; u < C2_U; ++u) {
-                    const int it = cur.it_beg + g * C2_U + u;
-                    if (it < cur.it_end) {
-                        const int tap = (it >= nk) + (it >= 2 * nk);
-                        const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
-                        const f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
-                        const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + plane);
-                        acc_lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_lh, 0, 0, 0);
-                        acc_hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_hl, 0, 0, 0);
-                        acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
-                    }
+                    const int it0 = cur.it_beg + g * C2_U + u;
+                    const bool ok = it0 < cur.it_end;
+                    const int it = max(min(it0, cur.it_end - 1), 0);
+                    const int tap = (it >= nk) + (it >= 2 * nk);
+                    const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
+                    f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
+                    f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + plane);
+                    if (!ok) { bh = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; bl = bh; }      // select, not a branch: 0 * w adds nothing
+                    acc_lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_lh, 0, 0, 0);
+                    acc_hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_hl, 0, 0, 0);
+                    acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
                 }
             };
-            const int P = max(C2_D, ((cur.ngroups + C2_D - 1) / C2_D) * C2_D);
+            const int P = ((cur.ngroups + C2_D - 1) / C2_D) * C2_D;       // ngroups >= 1
+            // do-while: the body runs at least once (P >= D), which lets the compiler prove that >= 24 weight loads
+            // are younger than the prefetched operand when the next block is staged (vmcnt(33), not vmcnt(9))
+            int g0 = 0;
 #pragma unroll 1
-            for (int g0 = 0; g0 < P; g0 += C2_D) {
+            do {
 #pragma unroll
                 for (int d = 0; d < C2_D; ++d) {
                     const int g = g0 + d;
-                    if (g < cur.ngroups) compute(ring[d], g);
+                    compute(ring[d], g);
+                    // refill this stage: group g + D of this block, or (last pass) group d of the next block, or a
+                    // harmless re-load — always issued
                     const int vg = g + C2_D;
-                    if (vg < cur.ngroups) load_group(ring[d], cur, vg);
-                    else if (has_next && vg >= P && vg - P < nxt.ngroups) load_group(ring[d], nxt, vg - P);
+                    const bool into_next = has_next && vg >= P;
+                    const _Float16 *rb = into_next ? nxt.base : cur.base;
+                    const int it0 = into_next ? nxt.it_beg + (vg - P) * C2_U : cur.it_beg + vg * C2_U;
+                    const int itl = into_next ? nxt.it_end - 1 : cur.it_end - 1;
+                    load_group(ring[d], rb, it0, itl);
                 }
-            }
+                g0 += C2_D;
+            } while (g0 < P);
         }
+        C2_STAMP_FIRST(5);
         if (!has_next) break;
         lds_bar();                   // every wave is done reading the slab
         ch = chn;
@@ -348,11 +387,13 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
         if constexpr (PREF) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[j] = vn[j];
+            ga = gan; be = ben;
         } else {
-            issue_operand(ch, v);
+            issue_operand(ch, v, ga, be);
         }
     }
     if (saturated) atomicAdd(A.sat, 1u);
+    C2_STAMP(6);
 
     // ---- sum the three product streams, then the k-parts of the workgroup (LDS) ------------------------
     f32x16 acc;
@@ -372,6 +413,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
             for (int r = 0; r < 16; ++r) acc[r] += srcp[r * 64 + lane];
         }
     }
+    C2_STAMP(7);
     // ---- cross-workgroup K reduction (hand-off recipe R1, cdna_hip_programming.md §6 G16): write-through
     //      partial tiles -> vmcnt(0) -> barrier -> relaxed ticket; the last arriver acquires and sums in slice order
     if (A.KS > 1) {
@@ -413,6 +455,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
             }
         }
     }
+    C2_STAMP(8);
     // ---- epilogue ---------------------------------------------------------------------------------------
     if (kpart == 0) {
         const int m = ct * 32 + (lane & 31);
@@ -421,9 +464,18 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Args A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = tile * 32 + frag_row(r, lane);
-            if (mok && co < A.Cout) A.out[b * A.out_bstride + (long)co * A.Lout + l] = acc[r] * inv_sc + pre_add[r];
+            if (mok && co < A.Cout) A.out[b * A.out_bstride + (long)co * A.Lout + l] = acc[r] * inv_sc + ((pre_b[r >> 2][r & 3] + (A.has_emb ? pre_e[r >> 2][r & 3] : 0.f)) + (A.has_res ? pre_r[r] : 0.f));
         }
     }
+#ifdef SURFD_C2_STAMPS
+    C2_STAMP(9);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    C2_STAMP(10);
+    if (A.dbg && blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 11; ++i) A.dbg[i] = stamp_[i];
+        A.dbg[15] = (long long)__builtin_readcyclecounter() - cyc0_;       // shader cycles over the same span
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -600,6 +652,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         while ((1 << S.log2Lin) < S.Lin) ++S.log2Lin;
         if (s == 0) Lin0 = S.Lin; else if (S.Lin != Lin0) return 1;
         S.taps = sp.taps; S.stride = sp.stride; S.ups = sp.ups; S.gn = sp.gn; S.act = sp.act;
+        S.gamma = S.beta = u->vecs;                  // always loaded (unconditional loads), used only with GroupNorm
         if (sp.gn) {
             S.gamma = u->vecs + u->vec_off[sp.gnkey + ".weight"]; S.beta = u->vecs + u->vec_off[sp.gnkey + ".bias"];
             S.gs = sp.C / 32;
@@ -612,6 +665,8 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.Lsl = max_lsl;
     const int VEC = Lin0 == 64 ? 16 : 8;
     int nb = std::min({B, (VEC * 4) / Lin0, std::max(1, 64 / A.Lout), 8});
+    // keep the slab under ~56 KB so that two workgroups (of this or of a concurrent sampling loop) share a CU
+    while (nb > 1 && (size_t)nb * A.Lsl * (max_blkp + 8) * 4 > 56 * 1024) --nb;
     if (nb * A.Lout > 64) return 1;
     A.bchunk = nb;
     A.cs = max_blkp + 8;
@@ -619,18 +674,23 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.plane = rows * A.cs;
     size_t lds = (size_t)A.plane * 2 * sizeof(_Float16);
     lds = (lds + 15) & ~(size_t)15;
+    // GroupNorm exchange area (staging) and k-part reduction scratch (after the last MFMA) are never live together
     A.off_ex = (int)lds;
-    lds += ((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float);
     A.off_red = (int)lds;
-    lds += (3 * 1024 + 4) * sizeof(float);
+    lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
     if (lds > 160 * 1024) return 1;
     A.whf = u->whf + c.whf_off; A.KS16 = c.KS16;
     A.sc = u->wsc + (size_t)c.sc_idx * 4;
     A.bias = u->vecs + c.bias_off;
+    A.emb = A.bias; A.emb_bstride = 0; A.res = A.bias; A.res_bstride = 0; A.res_cstride = 1; A.res_lstride = 0;
     if (c.emb_off >= 0 && io.emb) {
         A.emb = io.emb + c.emb_off; A.emb_bstride = io.emb_bs; A.step_ptr = io.step_ptr; A.emb_step_stride = (long)B * io.emb_bs;
+        A.has_emb = 1;
     }
-    if (c.res.buf != -1) { float *p; long bs; resolve(c.res, c.ds_out, false, p, bs); A.res = p; A.res_bstride = bs; }
+    if (c.res.buf != -1) {
+        float *p; long bs; resolve(c.res, c.ds_out, false, p, bs);
+        A.res = p; A.res_bstride = bs; A.res_cstride = A.Lout; A.res_lstride = 1; A.has_res = 1;
+    }
     { float *p; long bs; resolve(c.dst, c.ds_out, true, p, bs); A.out = p; A.out_bstride = bs; }
     A.ntiles = ceil_div(c.Cout, 32);
     A.nby = ceil_div(B, nb);
@@ -647,6 +707,12 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.KS = KS;
     A.part = u->part; A.counters = u->counters;
     A.sat = u->sat;
+    A.dbg = nullptr;
+    if (u->dbg && u->dbg_launch < 4096) {
+        A.dbg = u->dbg + (size_t)(u->dbg_launch++) * 16;
+        long long meta[4] = {c.Cout, c.seg[0].C + (c.nseg > 1 ? c.seg[1].C : 0), A.Lout * 100000LL + (long long)A.ntiles * A.nby * KS, KS * 100 + nch};
+        HIP_TRY(hipMemcpyAsync(A.dbg + 11, meta, sizeof(meta), hipMemcpyHostToDevice, st));
+    }
     const int G = A.ntiles * KS;
     dim3 grid((unsigned)(8 * ceil_div(G, 8) * A.nby));
     static const int pref = env_int("SURFD_CONV2_PREF", 1);

@@ -95,6 +95,16 @@ class MDM(nn.Module):
             self._bound_key = key
         return L, self._handle
 
+    def replica(self) -> "MDM":
+        """A second execution context over the SAME parameter tensors: its own native handle (workspace, embedding
+        table, captured loop graph), so independent sampling loops can run concurrently on different streams
+        (surfd_amd.parallel.BatchPipeline).  No reference counterpart (the reference samples one batch at a time)."""
+        import copy
+        other = copy.copy(self)              # shallow: _parameters / _buffers dicts are shared, not copied
+        other._handle = None
+        other._bound_key = None
+        return other
+
     def set_precision(self, mode: str) -> None:
         """'f16x2' (default: split-fp16 products on the fp16 matrix pipe, fp32 accumulation, operands clamped to the
         fp16 range and counted) or 'fp32' (exact fp32 MFMA) for the denoiser's convolutions."""

@@ -123,46 +123,58 @@ class ShardedField:
 
 
 class BatchPipeline:
-    """Software pipeline over independent batches on ONE GPU: the reverse loop of batch s+1 — a chain of
-    ~115 dependent, latency-bound launches per denoiser evaluation — runs on its own HIP stream while the
-    grids of batch s (matrix-pipe bound) are evaluated on another.  The decoder kernels are persistent (one
-    workgroup per CU), so the chip is split simply by their grid size (`CbnDecoder.set_grid_blocks`): while a
-    loop is in flight they take `decoder_blocks` CUs, for the last batch (nothing left to overlap) all of
-    them.  Results are identical to running the batches one after the other (tests/test_gpu_unet.py).
+    """Software pipeline over independent batches on ONE GPU.  One reverse loop is a chain of ~100 000 dependent,
+    latency-bound launches that keeps a fraction of the chip busy, so `loop_chains` loops (of different batches)
+    run concurrently, each on its own HIP stream and its own execution context (`MDM.replica()`: shared weights,
+    private workspace / captured graph), while the grids of finished batches (matrix-pipe bound) are evaluated on
+    another stream.  The decoder kernels are persistent (one workgroup per CU), so the chip is split simply by
+    their grid size (`CbnDecoder.set_grid_blocks`): while loops are in flight they take `decoder_blocks` CUs, once
+    no loop is left to overlap all of them.  Results are identical to running the batches one after the other
+    (tests/test_gpu_unet.py).
 
-        pipe = BatchPipeline(decoder, sample_fn, fill_fn, decoder_blocks=128)
+        pipe = BatchPipeline(decoder, sample_fn, fill_fn, decoder_blocks=160, loop_chains=2)
         pipe.run(n_batches)
 
-    sample_fn(s) -> latents        enqueues batch s's reverse loop on the current stream
-    fill_fn(s, latents) -> None    enqueues batch s's grid evaluation on the current stream
+    sample_fn(s, chain) -> latents   enqueues batch s's reverse loop on the current stream with context `chain`
+    fill_fn(s, latents) -> None      enqueues batch s's grid evaluation on the current stream
     """
 
-    def __init__(self, decoder, sample_fn, fill_fn, decoder_blocks: int = 128):
+    def __init__(self, decoder, sample_fn, fill_fn, decoder_blocks: int = 128, loop_chains: int = 1):
         self.decoder, self.sample_fn, self.fill_fn = decoder, sample_fn, fill_fn
         self.decoder_blocks = int(decoder_blocks)
-        self.loop_stream = torch.cuda.Stream()
+        self.loop_chains = max(1, int(loop_chains))
+        self.loop_streams = [torch.cuda.Stream() for _ in range(self.loop_chains)]
         self.fill_stream = torch.cuda.Stream()
 
     def run(self, n_batches: int) -> None:
+        Q = self.loop_chains
         cur = torch.cuda.current_stream()
-        self.loop_stream.wait_stream(cur)
+        for st in self.loop_streams:
+            st.wait_stream(cur)
         self.fill_stream.wait_stream(cur)
-        lat = [None, None]
-        done = [torch.cuda.Event(), torch.cuda.Event()]
+        lat = {}
+        done = {}
         try:
-            for s in range(n_batches + 1):
-                if s >= 1:      # grids of batch s-1: enqueued before the next loop call, which may block the host
-                    with torch.cuda.stream(self.fill_stream):
-                        self.fill_stream.wait_event(done[(s - 1) % 2])
-                        self.decoder.set_grid_blocks(self.decoder_blocks if s < n_batches else 0)
-                        self.fill_fn(s - 1, lat[(s - 1) % 2])
+            # host order: loop s is enqueued Q batches ahead of the grids that consume it, so Q loops are in
+            # flight while the grids of an older batch run; a loop call may block the host until its chain is idle
+            for s in range(n_batches + Q):
                 if s < n_batches:
-                    with torch.cuda.stream(self.loop_stream):
-                        x = self.sample_fn(s)
+                    q = s % Q
+                    with torch.cuda.stream(self.loop_streams[q]):
+                        x = self.sample_fn(s, q)
                         x.record_stream(self.fill_stream)
-                        lat[s % 2] = x
-                        done[s % 2].record(self.loop_stream)
+                        lat[s] = x
+                        done[s] = torch.cuda.Event()
+                        done[s].record(self.loop_streams[q])
+                f = s - Q
+                if f >= 0:
+                    with torch.cuda.stream(self.fill_stream):
+                        self.fill_stream.wait_event(done.pop(f))
+                        overlapped = f + 1 < n_batches            # some loop is still running next to these grids
+                        self.decoder.set_grid_blocks(self.decoder_blocks if overlapped else 0)
+                        self.fill_fn(f, lat.pop(f))
         finally:
             self.decoder.set_grid_blocks(0)
-            cur.wait_stream(self.loop_stream)
+            for st in self.loop_streams:
+                cur.wait_stream(st)
             cur.wait_stream(self.fill_stream)

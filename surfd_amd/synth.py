@@ -29,7 +29,11 @@ def _normal(shape, std, key, seed, mean=0.0):
     return torch.randn(tuple(shape), generator=_gen(key, seed), dtype=torch.float32) * std + mean
 
 
-def synth_unet_state_dict(cfg: UNetConfig = UNetConfig(), seed: int = 0, root: str = "Unet") -> Dict[str, torch.Tensor]:
+def synth_unet_state_dict(cfg: UNetConfig = UNetConfig(), seed: int = 0, root: str = "Unet",
+                          head_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """``head_gain`` scales the output head (``out.2``): with the default 1.0 the untrained map x_t -> x_{t-1} is
+    chaotic (fp noise grows exponentially over a 1000-step chain); ``CONTRACTIVE_HEAD_GAIN`` makes
+    |d x_{t-1} / d x_t| ~ coef2 < 1, so a 1000-step trajectory can be compared end to end."""
     sd: Dict[str, torch.Tensor] = {}
     for key, shape in unet_param_spec(cfg, root):
         leaf = key.rsplit(".", 1)[-1]
@@ -47,7 +51,12 @@ def synth_unet_state_dict(cfg: UNetConfig = UNetConfig(), seed: int = 0, root: s
                 fan_in *= s
             gain = 0.5 if (".out_layers.3." in key or ".proj_out." in key) else 1.0
             sd[key] = _normal(shape, gain / fan_in ** 0.5, key, seed)
+        if head_gain != 1.0 and key.startswith(f"{root}.out.2."):
+            sd[key] = sd[key] * head_gain
     return sd
+
+
+CONTRACTIVE_HEAD_GAIN = 0.05
 
 
 def synth_decoder_state_dict(cfg: DecoderConfig = DecoderConfig(), seed: int = 0) -> Dict[str, torch.Tensor]:

@@ -243,12 +243,14 @@ def test_batch_pipeline_matches_sequential():
     dec = CbnDecoder(63, 32, 512, 5)
     dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig(latent_dim=32)), strict=True)
     dec = dec.cuda().eval()
-    B, N, nb = 2, 64, 3
+    B, N, nb = 2, 64, 5
     filler = GridFiller(N)
     noise = [synth.synth_noise_batch(20, s * B, B, 32).cuda() for s in range(nb)]
+    chains = [model, model.replica()]          # two loops in flight: shared weights, private workspaces / graphs
 
-    def sample(s):
-        return dd.ddim_sample_loop(model, (B, 1, 32), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise[s], fused=True)
+    def sample(s, chain=0):
+        return dd.ddim_sample_loop(chains[chain], (B, 1, 32), clip_denoised=False, model_kwargs={"y": {}},
+                                   noise_stream=noise[s], fused=True)
 
     def make_fill(store):
         def fill(s, lat):
@@ -261,7 +263,7 @@ def test_batch_pipeline_matches_sequential():
     for s in range(nb):
         make_fill(seq)(s, sample(s))
     torch.cuda.synchronize()
-    BatchPipeline(dec, sample, make_fill(pip), decoder_blocks=96).run(nb)
+    BatchPipeline(dec, sample, make_fill(pip), decoder_blocks=96, loop_chains=2).run(nb)
     torch.cuda.synchronize()
     assert set(seq) == set(pip)
     for key in seq:
