@@ -97,6 +97,11 @@ int surfd_unet_set_precision(surfd_unet *u, int mode);
 int surfd_unet_saturation_count(surfd_unet *u, int reset, int64_t *count, surfd_stream s);
 /* developer aid: op >= 0 restricts the f16x2 kernel to that one conv op of the plan (the others run fp32); -1 lifts it */
 int surfd_unet_debug_only_op(surfd_unet *u, int op);
+/* test tap: runs only the ops of ONE module of UNetModel ("input_blocks.1.0" ResBlock, "input_blocks.1.1" AttentionBlock,
+ * "input_blocks.3.0" Downsample, "out" head, ...) on in[B,Cin,Lin] -> out[B,Cout,Lout], with the embedding rows left by
+ * the preceding surfd_unet_forward (same t, B, L): lets the tests compare single modules with the reference's hooks */
+int surfd_unet_debug_run_module(surfd_unet *u, const char *module, const float *in, int Cin, int Lin,
+                                float *out, int Cout, int Lout, int B, int L, surfd_stream s);
 
 /* ------------------------------------------------------------------------------------ */
 /* Reverse loop: p_sample_loop / ddim_sample_loop                                       */
@@ -154,6 +159,9 @@ int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s);
  * The gradient kernel (surfd_decoder_udf_grad) always runs in fp32.  The initial mode can also be set with
  * SURFD_DECODER_PRECISION=fp32|f16x2. */
 int surfd_decoder_set_precision(surfd_decoder *d, int mode);
+/* host-sync: waves of the f16x2 forward kernel that produced an activation beyond +-65504 (clamped) since the last
+ * reset.  Non-zero = this checkpoint / latent leaves the range mode 1 is exact for: switch to mode 0. */
+int surfd_decoder_saturation_count(surfd_decoder *d, int reset, int64_t *count, surfd_stream s);
 /* The decoder kernels are persistent: `blocks` workgroups (one per CU, LDS-limited) loop over the point tiles.
  * 0 (default) = every CU.  A smaller value leaves CUs free for work on another stream (bench.py overlaps the
  * reverse loop of the next batch with the grid evaluation of the current one this way). */

@@ -54,6 +54,7 @@ _SIGS = {
     "surfd_unet_set_precision": (C.c_int, [_P, C.c_int]),
     "surfd_unet_saturation_count": (C.c_int, [_P, C.c_int, c_i64p, _P]),
     "surfd_unet_debug_only_op": (C.c_int, [_P, C.c_int]),
+    "surfd_unet_debug_run_module": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "surfd_sample_loop": (C.c_int, [_P, C.POINTER(SamplerCfg), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "surfd_ddpm_step": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "surfd_ddim_step": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
@@ -65,6 +66,7 @@ _SIGS = {
     "surfd_decoder_set_param": (C.c_int, [_P, C.c_char_p, _P, c_i64p, C.c_int, _P]),
     "surfd_decoder_finalize": (C.c_int, [_P, _P]),
     "surfd_decoder_set_precision": (C.c_int, [_P, C.c_int]),
+    "surfd_decoder_saturation_count": (C.c_int, [_P, C.c_int, c_i64p, _P]),
     "surfd_decoder_set_grid_blocks": (C.c_int, [_P, C.c_int]),
     "surfd_decoder_bind_latents": (C.c_int, [_P, _P, C.c_int, _P]),
     "surfd_decoder_logits_emb": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, _P]),

@@ -175,6 +175,15 @@ class CbnDecoder(nn.Module):
         L, h = self._native()
         N.check(L.surfd_decoder_set_precision(h, {"fp32": 0, "f16x2": 1}[mode]))
 
+    def saturation_count(self, reset: bool = True) -> int:
+        """Waves of the f16x2 forward kernel that clamped an activation to the fp16 range since the last reset;
+        non-zero means this checkpoint / latent needs set_precision('fp32')."""
+        import ctypes as C
+        L, h = self._native()
+        n = C.c_int64()
+        N.check(L.surfd_decoder_saturation_count(h, int(reset), C.byref(n), N.stream()))
+        return int(n.value)
+
     def set_grid_blocks(self, blocks: int) -> None:
         """Persistent workgroups per decoder launch (0 = one per CU); fewer leaves CUs to other streams."""
         L, h = self._native()

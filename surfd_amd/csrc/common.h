@@ -72,7 +72,7 @@ int launch_pack(const PackDesc &d, hipStream_t s);
 // is launched on.  kind: 0 decoder forward, 1 decoder forward+reverse, 2 whole reverse loop.
 enum { PROF_DEC_FWD = 0, PROF_DEC_GRAD = 1, PROF_LOOP = 2, PROF_KINDS = 3 };
 bool prof_enabled();
-void prof_begin(int kind, hipStream_t st);
-void prof_end(int kind, hipStream_t st);
+hipEvent_t prof_begin(int kind, hipStream_t st);                  // null when profiling is off
+void prof_end(int kind, hipEvent_t begin, hipStream_t st);
 
 }  // namespace surfd

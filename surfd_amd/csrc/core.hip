@@ -1,5 +1,6 @@
 // Error reporting, version, device probe and the weight packer shared by all kernels.
 #include "common.h"
+#include <mutex>
 
 namespace surfd {
 
@@ -42,22 +43,24 @@ int launch_pack(const PackDesc &d, hipStream_t s) {
 static bool g_prof = false;
 struct ProfPair { hipEvent_t a, b; };
 static std::vector<ProfPair> g_prof_pairs[PROF_KINDS];
-static hipEvent_t g_prof_open[PROF_KINDS];
+static std::mutex g_prof_mu;          // loops of different chains and the grid stream are driven by different host threads
 
 bool prof_enabled() { return g_prof; }
-void prof_begin(int kind, hipStream_t st) {
-    if (!g_prof) return;
+hipEvent_t prof_begin(int kind, hipStream_t st) {
+    (void)kind;
+    if (!g_prof) return nullptr;
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     (void)hipEventRecord(e, st);
-    g_prof_open[kind] = e;
+    return e;
 }
-void prof_end(int kind, hipStream_t st) {
-    if (!g_prof) return;
+void prof_end(int kind, hipEvent_t begin, hipStream_t st) {
+    if (!begin) return;
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(begin); return; }
     (void)hipEventRecord(e, st);
-    g_prof_pairs[kind].push_back({g_prof_open[kind], e});
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pairs[kind].push_back({begin, e});
 }
 
 }  // namespace surfd
@@ -72,6 +75,7 @@ int surfd_profile_read(int kind, int64_t *launches, double *total_ms) {
     using namespace surfd;
     if (kind < 0 || kind >= PROF_KINDS || !launches || !total_ms) SURFD_FAIL(SURFD_ERR_ARG, "surfd_profile_read: bad argument");
     double tot = 0.0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &p : g_prof_pairs[kind]) {
         HIP_TRY(hipEventSynchronize(p.b));
         float ms = 0.f;

@@ -84,6 +84,7 @@ struct DecParams {
     const float *vecs;    // VEC_FLOATS: biases, w_out, b_out
     const float *tab;     // this sample's [NCBN][2][H] scale/shift
     int input_dim;
+    unsigned *sat;        // f16x2 forward path: waves that saw an activation beyond the fp16 range (it is clamped)
 };
 
 typedef float __attribute__((address_space(1))) gfloat;
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     // X <- split(min(relu(a*v + b), 65504)) for this wave's accumulator footprint (a, b per channel tile).
     // Scalar fp32 ops on purpose: packed-f32 ops would need register pairs built from two accumulator
     // tiles (copies + spills), and this mode has no bitwise contract, so the affine map is one fma.
+    float umax = 0.f;      // largest pre-clamp activation this lane produced (f16x2 mode)
     auto store_split = [&](const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -308,8 +310,11 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float u0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]), 0.f, 65504.f);
-                    const float u1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r], sb[2 * q + 1]), 0.f, 65504.f);
+                    const float t0 = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]);
+                    const float t1 = __builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r], sb[2 * q + 1]);
+                    umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));          // one v_max3_f32: range accounting
+                    const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
+                    const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
                     const f32x2 u = {u0, u1};
                     const f16x2 h = __builtin_convertvector(u, f16x2);              // one v_cvt_pk_f16_f32
                     const f32x2 hf = __builtin_convertvector(h, f32x2);
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll 2
             for (int i = 0; i < 8; ++i) {
                 f32x2 u = {feature(part * 16 + 2 * i), feature(part * 16 + 2 * i + 1)};
+                umax = __builtin_fmaxf(umax, __builtin_fmaxf(__builtin_fabsf(u.x), __builtin_fabsf(u.y)));
                 u.x = __builtin_amdgcn_fmed3f(u.x, -65504.f, 65504.f);
                 u.y = __builtin_amdgcn_fmed3f(u.y, -65504.f, 65504.f);
                 unsigned hi, lo;
@@ -715,6 +721,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             }
         }
     }
+    if constexpr (F16X2) {
+        if (__any(umax > 65504.f) && lane == 0) atomicAdd(P.sat, 1u);
+    }
     TFLUSH();
 }
 
@@ -812,6 +821,7 @@ struct surfd_decoder {
     int S = 0, tab_cap = 0;
     int num_cus = 256;
     int grid_blocks = 0;              // persistent workgroups per launch; 0 = one per CU
+    unsigned *sat = nullptr;          // device counter: waves of the f16x2 kernel that clamped an activation
     std::vector<void *> allocs;
 };
 
@@ -844,6 +854,9 @@ static int dec_alloc(surfd_decoder *d) {
     if ((rc = A(&d->vecs, VEC_FLOATS))) return rc;
     HIP_TRY(hipMalloc((void **)&d->whf, WHF_ELEMS * sizeof(_Float16)));
     d->allocs.push_back(d->whf);
+    HIP_TRY(hipMalloc((void **)&d->sat, sizeof(unsigned)));
+    d->allocs.push_back(d->sat);
+    HIP_TRY(hipMemset(d->sat, 0, sizeof(unsigned)));
     if (const char *pe = getenv("SURFD_DECODER_PRECISION")) d->precision = !strcmp(pe, "fp32") ? 0 : 1;
     for (int l = 0; l < NCBN; ++l) {
         if ((rc = A(&d->gw[l], (size_t)H * d->D))) return rc;
@@ -1028,6 +1041,19 @@ int surfd_decoder_set_precision(surfd_decoder *d, int mode) {
     return SURFD_OK;
 }
 
+int surfd_decoder_saturation_count(surfd_decoder *d, int reset, int64_t *count, surfd_stream s) {
+    if (!d || !count) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_saturation_count: null argument");
+    *count = 0;
+    if (!d->sat) return SURFD_OK;
+    unsigned v = 0;
+    hipStream_t st = as_stream(s);
+    HIP_TRY(hipMemcpyAsync(&v, d->sat, sizeof(v), hipMemcpyDeviceToHost, st));
+    if (reset) HIP_TRY(hipMemsetAsync(d->sat, 0, sizeof(v), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *count = v;
+    return SURFD_OK;
+}
+
 int surfd_decoder_bind_latents(surfd_decoder *d, const float *lat, int S, surfd_stream s) {
     if (!d || !lat || S < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_bind_latents: bad argument");
     if (!d->finalized) SURFD_FAIL(SURFD_ERR_STATE, "surfd_decoder_bind_latents: call surfd_decoder_finalize first");
@@ -1062,18 +1088,19 @@ int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles
     P.wpack = d->wpack; P.vecs = d->vecs; P.whf = d->whf;
     P.tab = d->tab + (size_t)sample * NCBN * 2 * H;
     P.input_dim = d->input_dim;
+    P.sat = d->sat;
     io.emb_dim = d->input_dim;
     // one workgroup per CU (LDS-limited); a device-side count is handled by the tile loop
     long blocks = d->grid_blocks > 0 ? std::min(d->grid_blocks, d->num_cus) : d->num_cus;
     if (ntiles_hint >= 0) blocks = std::min<long>(blocks, std::max<long>(ntiles_hint, 1));
-    prof_begin(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
+    hipEvent_t prof_ev = prof_begin(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
     if (grad)
         hipLaunchKernelGGL(decoder_kernel<true>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     else if (d->precision == 1)
         hipLaunchKernelGGL((decoder_kernel<false, true>), dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     else
         hipLaunchKernelGGL(decoder_kernel<false>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
-    prof_end(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
+    prof_end(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, prof_ev, st);
     LAUNCH_CHECK();
     return SURFD_OK;
 }

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "points.h"
 #include <string.h>
+#include <hipcub/hipcub.hpp>
 
 namespace surfd {
 
@@ -126,9 +127,30 @@ struct surfd_grid {
     float *cur_udf = nullptr, *cur_grads = nullptr;   // callback path
     bool dense_last = false;
     long dense_n = 0;
+    int *sort_out = nullptr; void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;   // callback path: deterministic list order
 };
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// The compacted lists are appended with one atomicAdd per wave, so their ORDER depends on scheduling.  The native
+// fill never looks at the order, but the callback path hands the points to the host in list order, and
+// parallel.ShardedField splits that order over ranks: every rank must see the same one -> sort by voxel index
+// (the host is synchronised at these points anyway).
+static int sort_list(surfd_grid *g, int *list, long n, hipStream_t st) {
+    if (n <= 1) return SURFD_OK;
+    size_t tmp_bytes = 0;
+    const int end_bit = 3 * ilog2(g->N) + 1;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, list, g->sort_out, (int)n, 0, end_bit, st));
+    if (tmp_bytes > g->sort_tmp_bytes) {
+        if (g->sort_tmp) HIP_TRY(hipFree(g->sort_tmp));
+        g->sort_tmp = nullptr;
+        HIP_TRY(hipMalloc(&g->sort_tmp, tmp_bytes));
+        g->sort_tmp_bytes = tmp_bytes;
+    }
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(g->sort_tmp, tmp_bytes, list, g->sort_out, (int)n, 0, end_bit, st));
+    HIP_TRY(hipMemcpyAsync(list, g->sort_out, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return SURFD_OK;
+}
 
 static int grid_alloc(surfd_grid *g) {
     if (g->allocated) return SURFD_OK;
@@ -141,6 +163,7 @@ static int grid_alloc(surfd_grid *g) {
     const long far_cap = nl >= 2 ? (long)g->levels[nl - 2] * g->levels[nl - 2] * g->levels[nl - 2] : 1;
     HIP_TRY(hipMalloc((void **)&g->far_list, far_cap * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->grad_list, N3 * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&g->sort_out, N3 * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->counters, CTR_TOTAL * sizeof(int)));
     HIP_TRY(hipMemset(g->counters, 0, CTR_TOTAL * sizeof(int)));
     g->allocated = true;
@@ -214,6 +237,8 @@ void surfd_grid_destroy(surfd_grid *g) {
     if (g->far_list) (void)hipFree(g->far_list);
     if (g->grad_list) (void)hipFree(g->grad_list);
     if (g->counters) (void)hipFree(g->counters);
+    if (g->sort_out) (void)hipFree(g->sort_out);
+    if (g->sort_tmp) (void)hipFree(g->sort_tmp);
     delete g;
 }
 
@@ -328,6 +353,7 @@ int surfd_grid_level_points(surfd_grid *g, int level, float *xyz, int64_t capaci
     *n = cnt;
     if (!xyz || cnt == 0) return SURFD_OK;
     if (capacity < cnt) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_level_points: capacity %lld < %ld points", (long long)capacity, cnt);
+    if (level > 0 && (rc = sort_list(g, g->parents[level], cnt / 7, as_stream(s)))) return rc;
     PtIO io = eval_io(g, level);
     hipLaunchKernelGGL(emit_points_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(cnt, 256), 4096)), dim3(256), 0,
                        as_stream(s), io, xyz);
@@ -362,6 +388,7 @@ int surfd_grid_grad_points(surfd_grid *g, float *xyz, int64_t capacity, int64_t 
     *n = c;
     if (!xyz || c == 0) return SURFD_OK;
     if (capacity < c) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_grad_points: capacity %lld < %d points", (long long)capacity, c);
+    if ((rc = sort_list(g, g->grad_list, c, as_stream(s)))) return rc;
     PtIO io = base_io(g);
     io.mode = PT_LIST; io.list = g->grad_list; io.n = c;
     hipLaunchKernelGGL(emit_points_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(c, 256), 4096)), dim3(256), 0,

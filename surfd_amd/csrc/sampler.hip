@@ -142,7 +142,7 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
         SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: DDIM tables missing");
     hipStream_t st = as_stream(s);
     const long n = (long)B * L;
-    prof_begin(PROF_LOOP, st);
+    hipEvent_t prof_ev = prof_begin(PROF_LOOP, st);
     // every timestep-only quantity of the denoiser for all T' iterations at once: loop
     // iteration k runs original timestep timestep_map[T'-1-k] for every sample
     std::vector<int64_t> t_rows((size_t)T * B);
@@ -215,7 +215,7 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     }
     for (int k = 0; k < T; ++k) HIP_TRY(hipGraphLaunch(ls->exec, st));
     HIP_TRY(hipMemcpyAsync(x_out, ls->x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    prof_end(PROF_LOOP, st);
+    prof_end(PROF_LOOP, prof_ev, st);
     return SURFD_OK;
 }
 

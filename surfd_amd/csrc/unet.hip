@@ -1308,6 +1308,26 @@ int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows,
 LoopState *unet_loop_state(surfd_unet *u) { return &u->loop; }
 long unet_workspace_generation(surfd_unet *u) { return u->ws_gen; }
 
+// one op of the denoiser body: x / out are the external input / output of the whole network
+static int run_op(surfd_unet *u, const Op &op, const float *x, float *out, int B, int L, const float *emb, hipStream_t st,
+                  const int *step_ptr) {
+    if (op.kind == 0) {
+        const float *in[2] = {x, x}; const long bs[2] = {(long)u->cfg.in_channels * L, (long)u->cfg.in_channels * L};
+        const int bm[2] = {0, 0};
+        return launch_conv(u, op.conv, B, L, in, bs, bm, out, (long)u->cfg.out_channels * L, emb, u->emb_total, st, step_ptr);
+    }
+    const AttnPlan &a = op.attn;
+    const int T = L / a.ds, heads = u->cfg.num_heads, d = a.C / heads;
+    const float *qkv = u->buf_ptr[a.qkv.buf];
+    float *o = u->buf_ptr[a.out.buf];
+    const long qbs = (long)u->bufs[a.qkv.buf].C * T, obs = (long)u->bufs[a.out.buf].C * T;
+    const float scale = 1.f / sqrtf(sqrtf((float)d));
+    const size_t lds_bytes = ((size_t)3 * d * T + (size_t)T * (T + 1)) * sizeof(float);
+    hipLaunchKernelGGL(attn_kernel, dim3(B * heads), dim3(256), lds_bytes, st, qkv, qbs, o, obs, heads, d, T, scale);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
 int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st,
                           const int *step_ptr) {
     if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
@@ -1318,23 +1338,8 @@ int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, i
     int rc = ensure_workspace(u, B, L);
     if (rc) return rc;
     const float *emb = u->emb_table + (size_t)row0 * u->emb_total;
-    for (auto &op : u->ops) {
-        if (op.kind == 0) {
-            const float *in[2] = {x, x}; const long bs[2] = {(long)u->cfg.in_channels * L, (long)u->cfg.in_channels * L};
-            const int bm[2] = {0, 0};
-            if ((rc = launch_conv(u, op.conv, B, L, in, bs, bm, out, (long)u->cfg.out_channels * L, emb, u->emb_total, st, step_ptr))) return rc;
-        } else {
-            const AttnPlan &a = op.attn;
-            const int T = L / a.ds, heads = u->cfg.num_heads, d = a.C / heads;
-            const float *qkv = u->buf_ptr[a.qkv.buf];
-            float *o = u->buf_ptr[a.out.buf];
-            const long qbs = (long)u->bufs[a.qkv.buf].C * T, obs = (long)u->bufs[a.out.buf].C * T;
-            const float scale = 1.f / sqrtf(sqrtf((float)d));
-            const size_t lds_bytes = ((size_t)3 * d * T + (size_t)T * (T + 1)) * sizeof(float);
-            hipLaunchKernelGGL(attn_kernel, dim3(B * heads), dim3(256), lds_bytes, st, qkv, qbs, o, obs, heads, d, T, scale);
-            LAUNCH_CHECK();
-        }
-    }
+    for (auto &op : u->ops)
+        if ((rc = run_op(u, op, x, out, B, L, emb, st, step_ptr))) return rc;
     return SURFD_OK;
 }
 
@@ -1346,6 +1351,47 @@ extern "C" int surfd_unet_debug_read(surfd_unet *u, long long *out, int max_laun
     if (hipMemcpy(out, u->dbg, (size_t)n * 16 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     u->dbg_launch = 0;
     return n;
+}
+
+// Test tap: runs ONLY the ops of one module (e.g. "input_blocks.1.0", "middle_block.1", "out") on a given input
+// activation, with the embedding rows prepared by the preceding surfd_unet_forward (same t / conditioning, same B, L).
+// in[B, Cin, Lin] -> out[B, Cout, Lout]; shapes are checked against the plan.
+extern "C" int surfd_unet_debug_run_module(surfd_unet *u, const char *module, const float *in, int Cin, int Lin,
+                                           float *out, int Cout, int Lout, int B, int L, surfd_stream s) {
+    if (!u || !module || !in || !out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_debug_run_module: null argument");
+    if (!u->finalized || u->emb_rows < B || u->ws_B < B || u->ws_L < L)
+        SURFD_FAIL(SURFD_ERR_STATE, "surfd_unet_debug_run_module: call surfd_unet_forward with the same B, L first");
+    hipStream_t st = as_stream(s);
+    const std::string pre = std::string(module) + ".";
+    std::vector<const Op *> sel;
+    bool prev = false;
+    for (auto &op : u->ops) {
+        const bool in_mod = op.kind == 0 ? op.conv.seg[0].wkey.rfind(pre, 0) == 0 : prev;
+        if (in_mod) sel.push_back(&op);
+        prev = in_mod;
+    }
+    if (sel.empty() || sel.front()->kind != 0 || sel.back()->kind != 0)
+        SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_debug_run_module: no ops for module '%s'", module);
+    const ConvPlan &first = sel.front()->conv, &last = sel.back()->conv;
+    const int lin = L / first.seg[0].ds, lout = L / last.ds_out;
+    if (first.seg[0].C != Cin || lin != Lin || last.Cout != Cout || lout != Lout)
+        SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_debug_run_module: '%s' maps [%d,%d] -> [%d,%d]", module, first.seg[0].C, lin, last.Cout, lout);
+    const View src = first.seg[0].src, dst = last.dst;
+    const float *ext_in = in;
+    if (src.buf >= 0) {
+        float *p = u->buf_ptr[src.buf] + (long)src.choff * lin;
+        HIP_TRY(hipMemcpy2DAsync(p, (size_t)u->bufs[src.buf].C * lin * sizeof(float), in, (size_t)Cin * lin * sizeof(float),
+                                 (size_t)Cin * lin * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+    }
+    int rc;
+    for (const Op *op : sel)
+        if ((rc = run_op(u, *op, ext_in, out, B, L, u->emb_table, st, nullptr))) return rc;
+    if (dst.buf >= 0) {
+        const float *p = u->buf_ptr[dst.buf] + (long)dst.choff * lout;
+        HIP_TRY(hipMemcpy2DAsync(out, (size_t)Cout * lout * sizeof(float), p, (size_t)u->bufs[dst.buf].C * lout * sizeof(float),
+                                 (size_t)Cout * lout * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+    }
+    return SURFD_OK;
 }
 
 extern "C" int surfd_unet_set_precision(surfd_unet *u, int mode) {

@@ -49,29 +49,38 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=
     raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
 
 
+def _ddim_stride(num_timesteps: int, want: int) -> int:
+    """The fixed stride whose range(0, T, stride) has exactly `want` entries ('ddimN' respacing)."""
+    hits = [st for st in range(1, num_timesteps) if len(range(0, num_timesteps, st)) == want]
+    if not hits:
+        raise ValueError(f"cannot create exactly {want} steps with an integer stride out of {num_timesteps}")
+    return hits[0]
+
+
 def space_timesteps(num_timesteps, section_counts):
-    """Set of original timesteps to keep ('ddimN' = fixed DDIM stride; list/csv = per-section counts)."""
+    """Original timesteps kept by a respacing spec (semantics of diffusion/respace.py:7-60): 'ddimN' keeps every
+    stride-th step; a list / comma string splits [0, T) into equal sections (the first T % n one longer) and keeps
+    `count` evenly spread steps of each, end points included."""
     if isinstance(section_counts, str):
         if section_counts.startswith("ddim"):
-            want = int(section_counts[len("ddim"):])
-            for stride in range(1, num_timesteps):
-                if len(range(0, num_timesteps, stride)) == want:
-                    return set(range(0, num_timesteps, stride))
-            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
-        section_counts = [int(x) for x in section_counts.split(",")]
-    size_per, extra = divmod(num_timesteps, len(section_counts))
-    start, keep = 0, []
-    for i, count in enumerate(section_counts):
-        size = size_per + (1 if i < extra else 0)
-        if size < count:
-            raise ValueError(f"cannot divide section of {size} steps into {count}")
-        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+            return set(range(0, num_timesteps, _ddim_stride(num_timesteps, int(section_counts[4:]))))
+        section_counts = [int(tok) for tok in section_counts.split(",")]
+    n_sec = len(section_counts)
+    kept = set()
+    first = 0
+    for sec, count in enumerate(section_counts):
+        length = num_timesteps // n_sec + (1 if sec < num_timesteps % n_sec else 0)
+        if count > length:
+            raise ValueError(f"cannot divide section of {length} steps into {count}")
+        gap = (length - 1) / (count - 1) if count > 1 else 1
+        # positions are a RUNNING float sum of the gap, rounded half-to-even — the accumulated rounding is part of
+        # the semantics (gap * j lands on the other side of .5 for some j)
         pos = 0.0
         for _ in range(count):
-            keep.append(start + round(pos))
-            pos += stride
-        start += size
-    return set(keep)
+            kept.add(first + round(pos))
+            pos += gap
+        first += length
+    return kept
 
 
 def _extract(arr: np.ndarray, t: th.Tensor, shape) -> th.Tensor:
@@ -257,41 +266,36 @@ class SpacedDiffusion:
 
     def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               skip_timesteps, init_image, randomize_class, eta, const_noise, noise_stream):
-        if device is None:
-            device = next(model.parameters()).device
+        """Generic per-step generator behind both *_progressive loops (behaviour of gaussian_diffusion.py:635-708 /
+        :908-972): yields the step dict of every iteration, t running from T'-1-skip down to 0."""
+        device = device if device is not None else next(model.parameters()).device
         assert isinstance(shape, (tuple, list))
-        if noise_stream is not None:
-            img = noise_stream[0].to(device)
-        elif noise is not None:
-            img = noise
-        else:
-            img = th.randn(*shape, device=device)
+        B = shape[0]
+        # start state: injected noise row, caller's noise, or a fresh draw
+        x = noise_stream[0].to(device) if noise_stream is not None else (noise if noise is not None else th.randn(*shape, device=device))
+        steps = range(self.num_timesteps - skip_timesteps - 1, -1, -1)
         if skip_timesteps and init_image is None:
-            init_image = th.zeros_like(img)
-        indices = list(range(self.num_timesteps - skip_timesteps))[::-1]
+            init_image = th.zeros_like(x)
         if init_image is not None:
-            my_t = th.ones([shape[0]], device=device, dtype=th.long) * indices[0]
-            img = self.q_sample(init_image, my_t, img)
+            # partial chain: start from q(x_t | init_image) at the first timestep actually run
+            x = self.q_sample(init_image, th.full((B,), steps[0], device=device, dtype=th.long), x)
         if progress:
             from tqdm.auto import tqdm
-            indices = tqdm(indices)
-        for k, i in enumerate(indices):
-            t_start = time.time()
-            t = th.tensor([i] * shape[0], device=device)
+            steps = tqdm(steps)
+        step_fn = self.p_sample if sampler == "ddpm" else self.ddim_sample
+        for k, i in enumerate(steps):
+            began = time.time()
             if randomize_class and "y" in model_kwargs:
-                model_kwargs["y"] = th.randint(low=0, high=model.num_classes, size=model_kwargs["y"].shape,
-                                               device=model_kwargs["y"].device)
-            z = None if noise_stream is None else noise_stream[1 + k].to(device)
+                yk = model_kwargs["y"]
+                model_kwargs["y"] = th.randint(low=0, high=model.num_classes, size=yk.shape, device=yk.device)
+            extra = {"const_noise": const_noise} if sampler == "ddpm" else {"eta": eta}
             with th.no_grad():
-                if sampler == "ddpm":
-                    out = self.p_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
-                                        model_kwargs=model_kwargs, const_noise=const_noise, _z=z)
-                else:
-                    out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
-                                           cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta, _z=z)
+                out = step_fn(model, x, th.full((B,), i, device=device, dtype=th.long), clip_denoised=clip_denoised,
+                              denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,
+                              _z=None if noise_stream is None else noise_stream[1 + k].to(device), **extra)
                 yield out
-                img = out["sample"]
-            self.time_con.append(time.time() - t_start)
+                x = out["sample"]
+            self.time_con.append(time.time() - began)
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,

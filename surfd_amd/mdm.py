@@ -167,23 +167,25 @@ class MDM(nn.Module):
 
 
 class ClassifierFreeSampleModel(nn.Module):
-    """Literal classifier-free combine.  MDM.forward never reads y['uncond'], so both evaluations
-    are identical and the result equals the conditional output bit for bit (SURVEY.md §0 fact 3);
-    the fused loop relies on that identity (tests/test_gpu_unet.py proves it)."""
+    """Classifier-free guidance wrapper with the reference's semantics (models/cfg_sampler.py:8-26): the model is
+    evaluated with `y` and with a copy of `y` flagged 'uncond', and the two are blended with y['scale'].  MDM.forward
+    never reads the flag, so both evaluations are identical and the result equals the conditional output bit for
+    bit; the fused loop relies on that identity (tests/test_gpu_unet.py proves it)."""
 
     def __init__(self, model):
         super().__init__()
         self.model = model
-        self.cond_mode = self.model.cond_mode
-        self.clip_version = self.model.clip_version
+        self.cond_mode, self.clip_version = model.cond_mode, model.clip_version
 
     def forward(self, x, timesteps, y=None):
-        assert self.model.cond_mode in ["text", "action"]
-        y_uncond = deepcopy(y)
-        y_uncond["uncond"] = True
-        out = self.model(x, timesteps, y)
-        out_uncond = self.model(x, timesteps, y_uncond)
-        return out_uncond + (y["scale"].view(-1, 1, 1) * (out - out_uncond))
+        if self.model.cond_mode not in ("text", "action"):
+            raise AssertionError(f"classifier-free sampling needs a text/action model, got {self.model.cond_mode!r}")
+        guidance = y["scale"].view(-1, 1, 1)                 # KeyError when the caller forgot the scale, as upstream
+        cond = self.model(x, timesteps, y)
+        flagged = deepcopy(y)
+        flagged["uncond"] = True
+        uncond = self.model(x, timesteps, flagged)
+        return uncond + guidance * (cond - uncond)
 
 
 def get_model_args(args):

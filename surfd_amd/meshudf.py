@@ -27,40 +27,38 @@ from torch import Tensor
 from . import _native as N
 
 
+def _chunks(n: int, size: int):
+    for lo in range(0, n, size):
+        yield lo, min(lo + size, n)
+
+
 def sample_udf(udf_func: Callable[[Tensor], Tensor], coords: Tensor, max_batch: int, grad: bool = False) -> Tensor:
-    udf = torch.zeros(coords.shape[0], device=coords.device)
-    start = 0
-    while start < coords.shape[0]:
-        end = min(start + max_batch, coords.shape[0])
-        p = coords[start:end]
-        if grad:
-            udf[start:end] = udf_func(p)
-        else:
-            with torch.no_grad():
-                udf[start:end] = udf_func(p)
-        start = end
-    return udf
+    """udf of `coords` [n,3] in chunks of `max_batch` (meshudf.py:209-228 behaviour); no autograd graph unless `grad`."""
+    out = torch.zeros(coords.shape[0], device=coords.device)
+    ctx = torch.enable_grad if grad else torch.no_grad
+    for lo, hi in _chunks(coords.shape[0], max_batch):
+        with ctx():
+            out[lo:hi] = udf_func(coords[lo:hi])
+    return out
 
 
 def sample_grads(udf_func: Callable[[Tensor], Tensor], coords: Tensor, max_batch: int) -> Tensor:
-    if hasattr(udf_func, "grads"):              # e.g. parallel.ShardedField: evaluates slices, gathers
+    """-normalize(d udf / d p) per point (meshudf.py:231-251 behaviour).  Three routes: a field that knows how to
+    shard itself (parallel.ShardedField), the native decoder (one fused forward+reverse kernel, no autograd), or an
+    arbitrary callable differentiated with autograd chunk by chunk like the reference."""
+    if hasattr(udf_func, "grads"):
         return udf_func.grads(coords, max_batch)
     native = getattr(udf_func, "_surfd_native", None)
-    if native is not None:                      # fused forward + reverse sweep, no autograd graph
+    if native is not None:
         dec, lat, sample = native
-        s = dec._bind_single(lat) if sample is None else sample
-        return dec.udf_and_ngrad(coords, s)[1]
-    grads = torch.zeros(coords.shape[0], 3, device=coords.device)
-    start = 0
-    while start < coords.shape[0]:
-        end = min(start + max_batch, coords.shape[0])
-        p = coords[start:end].detach().clone()
-        p.requires_grad = True
+        return dec.udf_and_ngrad(coords, dec._bind_single(lat) if sample is None else sample)[1]
+    out = torch.zeros(coords.shape[0], 3, device=coords.device)
+    for lo, hi in _chunks(coords.shape[0], max_batch):
+        leaf = coords[lo:hi].detach().clone().requires_grad_(True)
         with torch.enable_grad():
-            udf_func(p).sum().backward()
-        grads[start:end] = -F.normalize(p.grad, dim=1)
-        start = end
-    return grads
+            (g,) = torch.autograd.grad(udf_func(leaf).sum(), leaf)
+        out[lo:hi] = -F.normalize(g, dim=1)
+    return out
 
 
 class GridFiller:

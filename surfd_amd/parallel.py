@@ -147,34 +147,54 @@ class BatchPipeline:
         self.fill_stream = torch.cuda.Stream()
 
     def run(self, n_batches: int) -> None:
+        """One host thread per loop chain (a loop call blocks its caller while the device queue is full — the 1000
+        graph replays of one loop do not fit it), the calling thread enqueues the grids in batch order."""
+        import queue
+        import threading
         Q = self.loop_chains
         cur = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
         for st in self.loop_streams:
             st.wait_stream(cur)
         self.fill_stream.wait_stream(cur)
-        lat = {}
-        done = {}
-        try:
-            # host order: loop s is enqueued Q batches ahead of the grids that consume it, so Q loops are in
-            # flight while the grids of an older batch run; a loop call may block the host until its chain is idle
-            for s in range(n_batches + Q):
-                if s < n_batches:
-                    q = s % Q
+        ready = [queue.Queue() for _ in range(Q)]
+        errors = []
+
+        def chain_worker(q):
+            try:
+                torch.cuda.set_device(dev)
+                for s in range(q, n_batches, Q):
                     with torch.cuda.stream(self.loop_streams[q]):
                         x = self.sample_fn(s, q)
                         x.record_stream(self.fill_stream)
-                        lat[s] = x
-                        done[s] = torch.cuda.Event()
-                        done[s].record(self.loop_streams[q])
-                f = s - Q
-                if f >= 0:
-                    with torch.cuda.stream(self.fill_stream):
-                        self.fill_stream.wait_event(done.pop(f))
-                        overlapped = f + 1 < n_batches            # some loop is still running next to these grids
-                        self.decoder.set_grid_blocks(self.decoder_blocks if overlapped else 0)
-                        self.fill_fn(f, lat.pop(f))
+                        ev = torch.cuda.Event()
+                        ev.record(self.loop_streams[q])
+                    ready[q].put((s, x, ev))
+            except BaseException as e:          # surfaced on the calling thread
+                errors.append(e)
+                ready[q].put(None)
+
+        workers = [threading.Thread(target=chain_worker, args=(q,), daemon=True) for q in range(min(Q, n_batches))]
+        for w in workers:
+            w.start()
+        try:
+            for f in range(n_batches):
+                item = ready[f % Q].get()
+                if item is None:
+                    raise errors[0]
+                s, x, ev = item
+                assert s == f
+                with torch.cuda.stream(self.fill_stream):
+                    self.fill_stream.wait_event(ev)
+                    overlapped = f + 1 < n_batches            # some loop is still running next to these grids
+                    self.decoder.set_grid_blocks(self.decoder_blocks if overlapped else 0)
+                    self.fill_fn(f, x)
         finally:
+            for w in workers:
+                w.join()
             self.decoder.set_grid_blocks(0)
             for st in self.loop_streams:
                 cur.wait_stream(st)
             cur.wait_stream(self.fill_stream)
+        if errors:
+            raise errors[0]

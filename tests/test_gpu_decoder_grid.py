@@ -29,17 +29,19 @@ def _cos(a, b):
     return (a * b).sum(-1)
 
 
-def _check_directions(c):
-    """Stated tolerance on -normalize(grad udf): cosine >= 1 - 1e-5 for at least 99 % of the points.
-    The field is piecewise linear in 11 x 512 ReLU units; a point whose pre-activation is within fp32
-    rounding of a kink takes the other branch in a different-but-equally-valid fp32 evaluation order
-    (the reference's own fp32 autograd differs from an fp64 evaluation in the same way on ~0.1 % of
-    points), so a small fraction of finite jumps is expected and bounded, not forbidden."""
+def _check_directions(c, label=""):
+    """Stated tolerance on -normalize(grad udf): cosine >= 1 - 1e-5, asserted for >= 99.8 % of the
+    points — the measured level: the field is piecewise linear in 11 x 512 ReLU units, and a point whose
+    pre-activation is within fp32 rounding of a kink takes the other branch in a different-but-equally-valid fp32
+    evaluation order (the reference's own fp32 autograd differs from an fp64 evaluation the same way on ~0.1 % of
+    points).  The observed fraction and the worst cosine are printed with every run."""
     c = np.asarray(c)
     if c.size == 0:
         return
-    assert np.mean(c > 1 - 1e-5) >= 0.99, np.mean(c > 1 - 1e-5)
-    assert np.mean(c > 1 - 1e-3) >= 0.995 if c.size >= 200 else True
+    bad = int((c <= 1 - 1e-5).sum())
+    print(f"directions{label}: n={c.size} cos>1-1e-5 on {100.0 * (1 - bad / c.size):.3f} % of points, "
+          f"median 1-{1 - np.median(c):.1e}, worst cosine {c.min():.6f}")
+    assert bad <= max(1, int(np.ceil(0.002 * c.size))), (bad, c.size)
     assert np.median(c) > 1 - 1e-6
     assert c.min() > 0.9
 
@@ -202,11 +204,14 @@ def test_grid_callback_analytic_512_counts():
     torch.cuda.empty_cache()
 
 
-def test_grid_native_vs_golden_and_callback(golden):
+@pytest.mark.parametrize("D", [32, 64])
+def test_grid_native_vs_golden_and_callback(golden, D):
+    """GridFiller(64) with the native decoder against the grid the REFERENCE produced, for both latent widths
+    (D=64 is what configs C4 / C5 decode)."""
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
-    g = golden("g9_grid64_decoder")
-    dec, sd = _decoder(32)
+    g = golden("g9_grid64_decoder" if D == 32 else "g9_grid64_decoder_D64")
+    dec, sd = _decoder(D)
     lat = T(g["lat"]).cuda()
     f = make_udf_func(dec, lat)
     gf = GridFiller(64)
@@ -230,14 +235,15 @@ def test_grid_native_vs_golden_and_callback(golden):
     assert st_native["fwd_per_level"][0] == 32768 and st_native["fwd_per_level"][1] == 229376
 
 
-def test_grid_native_properties_256():
+@pytest.mark.parametrize("D", [32, 64])
+def test_grid_native_properties_256(D):
     """Full-size properties (no oracle can run this in seconds): per-level counts are
     self-consistent, pruned blocks are constant, every gradient is unit or zero and sits
-    exactly on the voxels below the gradient threshold."""
+    exactly on the voxels below the gradient threshold.  D=64: the decoder of configs C4 / C5."""
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
-    dec, sd = _decoder(32)
-    lat = (torch.randn(1, 32, generator=torch.Generator().manual_seed(9)) * 0.8).cuda()
+    dec, sd = _decoder(D)
+    lat = (torch.randn(1, D, generator=torch.Generator().manual_seed(9)) * 0.8).cuda()
     gf = GridFiller(256)
     udf, grads = gf.fill_grid(make_udf_func(dec, lat), 2 ** 16)
     st = gf.last_stats
@@ -344,3 +350,87 @@ def test_decoder_f16x2_vs_fp32_kernel(golden):
     # saturation instead of inf for absurd inputs (documented range limit of the mode)
     far = torch.full((64, 3), 3.0e4, device="cuda")
     assert torch.isfinite(dec._logits_xyz(far, 0)).all()
+
+
+def test_grid_512_properties_D64():
+    """Configs C4 / C5 at their real grid size: 512^3 coarse-to-fine fill with the D=64 decoder — level counts,
+    gradient support, unit norms, idempotence and direct re-evaluation of sampled voxels."""
+    from surfd_amd.cbndec import make_udf_func
+    from surfd_amd.meshudf import GridFiller
+    dec, sd = _decoder(64)
+    lat = (torch.randn(1, 64, generator=torch.Generator().manual_seed(19)) * 0.8).cuda()
+    gf = GridFiller(512)
+    udf, grads = gf.fill_grid(make_udf_func(dec, lat), 2 ** 16)
+    st = gf.last_stats
+    assert st["levels"] == [32, 64, 128, 256, 512]
+    assert st["fwd_per_level"][0] == 32 ** 3 and st["fwd_per_level"][1] == 7 * 32 ** 3
+    assert all(c % 7 == 0 for c in st["fwd_per_level"][1:])
+    gnorm = grads.norm(dim=-1)
+    has = gnorm > 0
+    assert int(has.sum()) <= st["grad"] and bool((udf[has] < 2.5 * 2.0 / 512).all())
+    assert torch.allclose(gnorm[has], torch.ones_like(gnorm[has]), atol=1e-5)
+    checksum = float(udf.double().sum())
+    udf2, grads2 = gf.fill_grid(make_udf_func(dec, lat), 2 ** 16)
+    assert float(udf2.double().sum()) == checksum and torch.equal(udf, udf2) and torch.equal(grads, grads2)
+    idx = torch.randint(0, 512 ** 3, (50000,), generator=torch.Generator().manual_seed(2))
+    i, j, k = idx // (512 * 512), (idx // 512) % 512, idx % 512
+    ax = ogrid.axis_coords(512)
+    direct = dec.udf(torch.stack([ax[i], ax[j], ax[k]], 1).cuda(), 0)
+    stored = udf.reshape(-1)[idx.cuda()]
+    same = direct == stored
+    assert bool((stored[~same] >= float(torch.tensor(1.5 * 1.7 * (2.0 / 256), dtype=torch.float32))).all())
+    assert dec.saturation_count() == 0
+    del udf, grads, udf2, grads2
+    torch.cuda.empty_cache()
+
+
+def test_decoder_saturation_is_counted():
+    """f16x2 clamps activations at 65504; that must never be silent: the counter reports it, fp32 mode has no limit."""
+    dec, _ = _decoder(32)
+    pts = (torch.rand(4096, 3, generator=torch.Generator().manual_seed(3)) * 2 - 1).cuda()
+    dec.bind_latents((torch.randn(1, 32, generator=torch.Generator().manual_seed(4)) * 0.8).cuda())
+    dec.udf(pts, 0)
+    assert dec.saturation_count() == 0
+    dec.bind_latents(torch.full((1, 32), 3.0e5).cuda())      # conditional-BN scales ~1e5 -> activations beyond fp16
+    dec.udf(pts, 0)
+    assert dec.saturation_count() > 0
+    dec.set_precision("fp32")
+    try:
+        u = dec.udf(pts, 0)
+        assert torch.isfinite(u).all() and dec.saturation_count() == 0
+    finally:
+        dec.set_precision("f16x2")
+
+
+def test_callback_point_lists_are_in_voxel_order():
+    """the device lists are appended with per-wave atomics (scheduling-dependent order); what the
+    callback path hands to the host — and parallel.ShardedField splits over ranks by position — must be a
+    deterministic order: ascending voxel index for the gradient points, ascending parent corner for level points."""
+    from surfd_amd.meshudf import GridFiller
+    N = 128
+    seen = []
+
+    def field(c):
+        seen.append(c.clone())
+        return ogrid.analytic_field(c.cpu()).cuda()
+
+    class WithGrads:
+        def __call__(self, c):
+            return field(c)
+
+        def grads(self, c, max_batch):
+            seen.append(c.clone())
+            return torch.zeros(c.shape[0], 3, device=c.device)
+
+    GridFiller(N).fill_grid(WithGrads(), 2 ** 30)
+    vox = 2.0 / (N - 1)
+
+    def flat(c):
+        ijk = torch.round((c.double() + 1.0) / vox).long()
+        return (ijk[:, 0] * N + ijk[:, 1]) * N + ijk[:, 2]
+    gradpts = seen[-1]
+    f = flat(gradpts)
+    assert bool((f[1:] > f[:-1]).all()), "gradient points are not in ascending voxel order"
+    for lvl_pts in seen[1:-1]:                          # levels >= 1: 7 children per parent, parents ascending
+        corners = flat(lvl_pts.reshape(-1, 7, 3)[:, 0, :])
+        assert bool((corners[1:] > corners[:-1]).all())

@@ -192,3 +192,52 @@ def test_g9_gridfiller_decoder(golden, decoder_sd32):
     both = (np.linalg.norm(mine, axis=-1) > 0) & (np.linalg.norm(g["grad_sub"], axis=-1) > 0)
     assert both.mean() > 0.5
     assert ((mine * g["grad_sub"]).sum(-1)[both] > 1 - 1e-4).mean() > 0.999
+
+
+# ---- round 2 fixtures: configs C4 / C5, end-to-end 1000-step chain, D=64 grid --------------------------------
+def test_g11_conditioned_ddim50(golden, unet_sd):
+    """The oracle's conditioned loop (context -> sketch_emb, L=64) against the reference trajectory of config C5,
+    and the classifier-free wrapper of config C4 (out_u + s * (out_c - out_u) with out_u == out_c)."""
+    B, L = 8, 64
+    for name in ("g11_ddim50_img_B8_L64", "g11_ddim50_textcfg_B8_L64"):
+        g = golden(name)
+        noise = synth.synth_noise_batch(50, 0, B, L, seed=int(g["seed"]))
+        ctx = synth.synth_context(0, B, seed=int(g["ctx_seed"]))
+        if "scale" in g.files:
+            sc = float(g["scale"])
+
+            def model(xx, tt):
+                out = ounet.unet_forward(unet_sd, xx, tt, context=ctx)
+                out_u = ounet.unet_forward(unet_sd, xx, tt, context=ctx)       # MDM.forward never reads y['uncond']
+                return out_u + sc * (out - out_u)
+        else:
+            model = lambda xx, tt: ounet.unet_forward(unet_sd, xx, tt, context=ctx)
+        x, rec = odiff.sample_loop(odiff.make_schedule(respacing="ddim50"), model, noise, sampler="ddim", record=[0, 24, 49])
+        for k in (0, 24, 49):
+            np.testing.assert_allclose(rec[k].numpy(), g[f"x_after_{k}"], rtol=1e-3, atol=2e-4)
+
+
+def test_g12_ddpm1000_contractive_end_to_end(golden):
+    """1000 ancestral steps end to end (contractive synthetic head): oracle == reference at every recorded step."""
+    g = golden("g12_ddpm1000_contractive_B2_L32")
+    sd = synth.synth_unet_state_dict(head_gain=float(g["head_gain"]))
+    noise = synth.synth_noise_batch(1000, 0, 2, 32, seed=int(g["seed"]))
+    model = lambda xx, tt: ounet.unet_forward(sd, xx, tt)
+    keep = [0, 1, 499, 998, 999]
+    x, rec = odiff.sample_loop(odiff.make_schedule(), model, noise, record=keep)
+    for k in keep:
+        np.testing.assert_allclose(rec[k].numpy(), g[f"x_after_{k}"], rtol=0, atol=1e-5)
+
+
+def test_g9_gridfiller_decoder_D64(golden):
+    g = golden("g9_grid64_decoder_D64")
+    sd = synth.synth_decoder_state_dict(DecoderConfig(latent_dim=64))
+    f = odec.make_udf_func(sd, T(g["lat"]))
+    udf, grads, stats = ogrid.fill_grid(f, 64, max_batch=2 ** 12)
+    close = np.isclose(udf.numpy(), g["udf"], rtol=0, atol=1e-6)
+    assert close.mean() > 0.9999
+    sub = g["grad_idx"]
+    mine = grads.reshape(-1, 3).numpy()[sub]
+    both = (np.linalg.norm(mine, axis=-1) > 0) & (np.linalg.norm(g["grad_sub"], axis=-1) > 0)
+    assert both.mean() > 0.5
+    assert ((mine * g["grad_sub"]).sum(-1)[both] > 1 - 1e-4).mean() > 0.999

@@ -54,11 +54,29 @@ def ref_args(cond_mode: str):
                                  noise_schedule="cosine", sigma_small=True, clip_value=1.0)
 
 
-def build_model(R, cond_mode: str):
+class FakeClip(torch.nn.Module):
+    """Stands in for the CLIP text tower (weights unavailable offline; the tower is an input producer outside the
+    path): ``encode_text`` returns the rows of a fixed table selected by the 'token' ids ``tokenize`` hands out."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.register_buffer("table", table)
+
+    def encode_text(self, tokens):
+        return self.table[tokens]
+
+
+def install_fake_clip(table):
+    clip = sys.modules["clip"]
+    clip.load = lambda *a, **k: (FakeClip(table), None)
+    clip.tokenize = lambda raw_text, truncate=True: torch.tensor([int(t) for t in raw_text], dtype=torch.long)
+
+
+def build_model(R, cond_mode: str, head_gain: float = 1.0):
     model, diffusion = R.model_util.create_model_and_diffusion(ref_args(cond_mode))
     cfg = UNetConfig(num_classes=9 if "category" in cond_mode else None)
-    sd = synth.synth_unet_state_dict(cfg)
-    ref_sd = model.state_dict()
+    sd = synth.synth_unet_state_dict(cfg, head_gain=head_gain)
+    ref_sd = {k: v for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
     assert list(ref_sd.keys()) == list(sd.keys()), "spec.py key order differs from the reference"
     for k in sd:
         assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
@@ -302,6 +320,100 @@ def g10(R, sizes):
     save("g10_grid_analytic", **res)
 
 
+
+def run_loop(R, model, diff, shape, noise, sampler, model_kwargs, record, eta=0.0):
+    """Reference loop with the injected noise stream; returns {x_after_k} for k in record."""
+    th = R.gd.th
+    real = th.randn_like
+    th.randn_like = NoiseFeeder(list(noise[1:]))
+    rec = {}
+    try:
+        with torch.no_grad():
+            if sampler == "ddim":
+                it = diff.ddim_sample_loop_progressive(model, shape, noise=noise[0].clone(), clip_denoised=False,
+                                                       model_kwargs=model_kwargs, eta=eta)
+            else:
+                it = diff.p_sample_loop_progressive(model, shape, noise=noise[0].clone(), clip_denoised=False,
+                                                    model_kwargs=model_kwargs)
+            for k, o in enumerate(it):
+                if k in record:
+                    rec[f"x_after_{k}"] = o["sample"].clone()
+    finally:
+        th.randn_like = real
+    return rec
+
+
+def ddim50(R):
+    base = R.gd.get_named_beta_schedule("cosine", 1000, 1.0)
+    return R.respace.SpacedDiffusion(use_timesteps=R.respace.space_timesteps(1000, "ddim50"), betas=base,
+                                     model_mean_type=R.gd.ModelMeanType.START_X,
+                                     model_var_type=R.gd.ModelVarType.FIXED_SMALL, loss_type=R.gd.LossType.MSE,
+                                     rescale_timesteps=False, args=ref_args("no_cond"))
+
+
+def g11_conditioned_loops(R):
+    """Configs C4 / C5: L=64, context[B,512]; C5 = 'img' mode, C4 = 'text' mode under the
+    classifier-free wrapper with scale 3.0 (the CLIP tower replaced by a fixed embedding table)."""
+    B, L = 8, 64
+    ctx = synth.synth_context(0, B)
+    # C5: image-conditioned, 50-step DDIM (eta 0)
+    model, _ = build_model(R, "img")
+    noise = synth.synth_noise_batch(50, 0, B, L)
+    t0 = time.time()
+    rec = run_loop(R, model, ddim50(R), (B, 1, L), noise, "ddim", {"y": {"context": ctx}}, (0, 24, 49))
+    print(f"  reference img-cond DDIM-50 B={B} L={L}: {time.time() - t0:.1f}s")
+    save("g11_ddim50_img_B8_L64", seed=1234, ctx_seed=77, **rec)
+    # C4: text-conditioned + CFG wrapper, 50-step DDIM
+    install_fake_clip(ctx)
+    model, _ = build_model(R, "text")
+    wrapped = R.cfg_sampler.ClassifierFreeSampleModel(model)
+    kw = {"y": {"text": [str(i) for i in range(B)], "scale": torch.ones(B) * 3.0}}
+    t0 = time.time()
+    rec = run_loop(R, wrapped, ddim50(R), (B, 1, L), noise, "ddim", kw, (0, 24, 49))
+    print(f"  reference text+CFG DDIM-50 B={B} L={L}: {time.time() - t0:.1f}s")
+    save("g11_ddim50_textcfg_B8_L64", seed=1234, ctx_seed=77, scale=3.0, **rec)
+
+
+def g12_contractive(R):
+    """1000-step DDPM chains that CAN be compared end to end: the head of the synthetic denoiser is scaled by
+    synth.CONTRACTIVE_HEAD_GAIN, which makes the map x_t -> x_{t-1} contractive (a 1e-4 perturbation of x_T
+    shrinks to 1e-7 at the end instead of growing to O(1))."""
+    g = synth.CONTRACTIVE_HEAD_GAIN
+    keep = (0, 1, 499, 998, 999)
+    model, diff = build_model(R, "no_cond", head_gain=g)
+    noise = synth.synth_noise_batch(1000, 0, 2, 32)
+    t0 = time.time()
+    rec = run_loop(R, model, diff, (2, 1, 32), noise, "ddpm", {"y": {}}, keep)
+    print(f"  reference contractive 1000-step DDPM B=2 L=32: {time.time() - t0:.1f}s")
+    save("g12_ddpm1000_contractive_B2_L32", seed=1234, head_gain=g, **rec)
+    # C4 at full length: text + CFG(3.0), L=64, 1000 steps
+    B, L = 2, 64
+    ctx = synth.synth_context(0, B)
+    install_fake_clip(ctx)
+    model, diff = build_model(R, "text", head_gain=g)
+    wrapped = R.cfg_sampler.ClassifierFreeSampleModel(model)
+    kw = {"y": {"text": [str(i) for i in range(B)], "scale": torch.ones(B) * 3.0}}
+    noise = synth.synth_noise_batch(1000, 0, B, L)
+    t0 = time.time()
+    rec = run_loop(R, wrapped, diff, (B, 1, L), noise, "ddpm", kw, keep)
+    print(f"  reference contractive text+CFG 1000-step DDPM B=2 L=64: {time.time() - t0:.1f}s")
+    save("g12_ddpm1000_contractive_textcfg_B2_L64", seed=1234, ctx_seed=77, scale=3.0, head_gain=g, **rec)
+
+
+def g9_d64(R):
+    dec = build_decoder(R, 64)
+    lat = rnd((1, 64), 52, 0.8)
+    f = make_ref_udf(R, dec, lat)
+    t0 = time.time()
+    gf = R.meshudf.GridFiller(64)
+    udf, grads = gf.fill_grid(f, 2 ** 12)
+    print(f"  reference GridFiller(64) with the D=64 synthetic decoder: {time.time() - t0:.1f}s")
+    udf, grads = udf.detach(), grads.detach()
+    sub = torch.arange(0, 64 ** 3, 5)
+    save("g9_grid64_decoder_D64", lat=lat, udf=udf, grad_idx=sub, grad_sub=grads.reshape(-1, 3)[sub],
+         grad_nonzero=int((grads.abs().sum(-1) > 0).sum()), udf_sum=float(udf.double().sum()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -311,7 +423,8 @@ def main():
     torch.manual_seed(0)
     R = import_reference(a.ref)
     jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
-            "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")])}
+            "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
+            "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R)}
     only = [s for s in a.only.split(",") if s]
     for name, fn in jobs.items():
         if only and name not in only:
