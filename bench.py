@@ -62,12 +62,12 @@ def parse():
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--decoder-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="forward decoder kernel arithmetic (include/surfd_hip.h: surfd_decoder_set_precision)")
-    ap.add_argument("--decoder-blocks", type=int, default=160,
+    ap.add_argument("--decoder-blocks", type=int, default=208,
                     help="with --pipeline 1: persistent decoder workgroups per launch while the next batch's reverse loop "
                          "runs on the remaining CUs (the last batch's grids, with nothing left to overlap, use every CU)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: overlap the reverse loops of the next batches with the grid evaluation of the current one")
-    ap.add_argument("--loop-chains", type=int, default=2,
+    ap.add_argument("--loop-chains", type=int, default=3,
                     help="with --pipeline 1: reverse loops (of different batches) in flight at once, each on its own stream "
                          "and execution context (MDM.replica)")
     ap.add_argument("--unet-precision", choices=["f16x2", "fp32"], default="f16x2",

@@ -302,8 +302,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     // X <- split(min(relu(a*v + b), 65504)) for this wave's accumulator footprint (a, b per channel tile).
     // Scalar fp32 ops on purpose: packed-f32 ops would need register pairs built from two accumulator
     // tiles (copies + spills), and this mode has no bitwise contract, so the affine map is one fma.
-    float umax = 0.f;      // largest pre-clamp activation this lane produced (f16x2 mode)
+    int sat_flag = 0;      // wave-uniform: some lane of this wave produced an activation beyond the fp16 range (f16x2 mode)
     auto store_split = [&](const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4]) {
+        float umax = 0.f;  // local to one epilogue: a value kept across the GEMM loops would cost spills in the hot loop
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                     XW(mt, q, r, 0) = __builtin_bit_cast(unsigned, h);
                     XW(mt, q, r, 1) = __builtin_bit_cast(unsigned, l);
                 }
+        sat_flag |= __any(umax > 65504.f);
     };
 
     WStages ws;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll 2
             for (int i = 0; i < 8; ++i) {
                 f32x2 u = {feature(part * 16 + 2 * i), feature(part * 16 + 2 * i + 1)};
-                umax = __builtin_fmaxf(umax, __builtin_fmaxf(__builtin_fabsf(u.x), __builtin_fabsf(u.y)));
+                sat_flag |= __any(__builtin_fmaxf(__builtin_fabsf(u.x), __builtin_fabsf(u.y)) > 65504.f);
                 u.x = __builtin_amdgcn_fmed3f(u.x, -65504.f, 65504.f);
                 u.y = __builtin_amdgcn_fmed3f(u.y, -65504.f, 65504.f);
                 unsigned hi, lo;
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
         }
     }
     if constexpr (F16X2) {
-        if (__any(umax > 65504.f) && lane == 0) atomicAdd(P.sat, 1u);
+        if (sat_flag && lane == 0) atomicAdd(P.sat, 1u);
     }
     TFLUSH();
 }
