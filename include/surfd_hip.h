@@ -225,6 +225,29 @@ int surfd_grid_level_commit(surfd_grid *g, int level, const float *values, int64
 int surfd_grid_grad_points(surfd_grid *g, float *xyz, int64_t capacity, int64_t *n, surfd_stream s);
 int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_stream s);
 
+/* ------------------------------------------------------------------------------------ */
+/* UDF marching cubes (host side, no device): udf_mc_lewiner / marching_cubes_udf        */
+/* (meshudf/_marching_cubes_lewiner.py:87-154, meshudf/_marching_cubes_lewiner_cy.pyx:1115-1775) */
+/* ------------------------------------------------------------------------------------ */
+typedef struct surfd_mc surfd_mc;
+/* udf[nz,ny,nx] and grads[nz,ny,nx,3] are HOST arrays (the grids of surfd_grid_fill copied back, udf clamped at 0).
+ * Meshes the zero set: signs of the cube corners are voted from the gradient field, cubes are triangulated with
+ * Lewiner et al.'s case tables.  Output bit-identical to the reference extension.  One shape per call, one thread. */
+int surfd_mc_udf(const float *udf, const float *grads, int nz, int ny, int nx, int step, surfd_mc **out);
+/* Level-set marching cubes over the whole volume (watertight path: sample/generate_text.py:139-141 extracts the 0.01
+ * level with PyMCubes).  classic != 0: the original 256-case triangle table (PyMCubes' algorithm); 0: Lewiner's
+ * disambiguated cases.  Same result accessors as surfd_mc_udf. */
+int surfd_mc_iso(const float *volume, int nz, int ny, int nx, double level, int classic, int step, surfd_mc **out);
+int64_t surfd_mc_num_vertices(const surfd_mc *m);
+int64_t surfd_mc_num_faces(const surfd_mc *m);
+/* vertices[V,3] in (z,y,x) voxel units, faces[F,3] (winding of gradient_direction="descent"), normals[V,3] (unit),
+ * values[V]; any pointer may be NULL */
+int surfd_mc_copy(const surfd_mc *m, float *vertices, int32_t *faces, float *normals, float *values);
+void surfd_mc_destroy(surfd_mc *m);
+/* the case tables the library was built with (Lewiner et al. 2003), for tests */
+int surfd_mc_lut_count(void);
+int surfd_mc_lut(int i, const char **name, const signed char **values, int *ndim, int dims[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,14 @@ _SIGS = {
     "surfd_grid_level_commit": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
     "surfd_grid_grad_points": (C.c_int, [_P, _P, C.c_int64, c_i64p, _P]),
     "surfd_grid_grad_commit": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "surfd_mc_udf": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "surfd_mc_iso": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),
+    "surfd_mc_num_vertices": (C.c_int64, [_P]),
+    "surfd_mc_num_faces": (C.c_int64, [_P]),
+    "surfd_mc_copy": (C.c_int, [_P, _P, _P, _P, _P]),
+    "surfd_mc_destroy": (None, [_P]),
+    "surfd_mc_lut_count": (C.c_int, []),
+    "surfd_mc_lut": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_byte)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsurfd_hip.so")
-SOURCES = ["core.hip", "decoder.hip", "grid.hip", "unet.hip", "conv_f16x2.hip", "sampler.hip"]
+SOURCES = ["core.hip", "decoder.hip", "grid.hip", "unet.hip", "conv_f16x2.hip", "sampler.hip", "mcubes.cpp"]   # .cpp = host-only code
 # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so with the default
 # "fast" contraction the compiler would fuse the separately rounded steps that mirror torch's
 # fp32 op sequence (grid coordinates, posterior updates) into FMAs.
@@ -46,13 +46,16 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(LIBDIR, "obj", s.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, "obj", os.path.splitext(s)[0] + ".o")
         if force or _newer(obj, [src] + headers):
             jobs.append((src, obj))
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if src.endswith(".cpp"):      # host-only translation unit: no offload
+            cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-c", src, "-o", obj]
+        else:
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
@@ -61,7 +64,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
-    objs = [os.path.join(LIBDIR, "obj", s.replace(".hip", ".o")) for s in srcs]
+    objs = [os.path.join(LIBDIR, "obj", os.path.splitext(s)[0] + ".o") for s in srcs]
     if force or jobs or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,653 @@
+// UDF marching cubes on the host: the mesh-extraction stage behind the grids.
+//
+// Replaces the reference's Cython extension meshudf/_marching_cubes_lewiner_cy.pyx:
+//   marching_cubes_udf (:1115-1775)  raster scan for seed cubes + breadth-first growth in which the corners of every
+//                                    near-surface cube get a SIGN by letting already-signed neighbours vote through
+//                                    the UDF gradients (compute_edge_vote :1778-1806), deferral queues for unsure
+//                                    votes and for ambiguous marching-cubes cases;
+//   Cell (:86-852)                   vertex cache per cube edge, vertex interpolation, gradient-accumulated normals;
+//   the_big_switch / check_the_big_switch (:1845-2390), test_face (:2403-2431), test_internal (:2434-2569)
+//                                    Lewiner et al.'s case analysis with topological guarantees (tables: mc_luts.h).
+// Output is bit-identical to the reference (faces exactly, vertices as the same float32 values): every arithmetic step
+// keeps the reference's type (float votes, double interpolation, float stores) and order, including two quirks that
+// shape the result — the interior vertex' gradient writes its z-sum into the x slot (pyx:842-849) and the anchor
+// vector survives from cube to cube when every corner gradient is zero (pyx:1352).
+//
+// What is different: the reference allocates 4 ints per voxel for the edge->vertex cache (2.1 GB at 512^3, filled
+// with -1 up front); here the cache is paged and pages appear on first touch (the surface band is ~1 % of the grid),
+// and the sign / state volumes are calloc'ed (zero pages are only materialised where the band touches them).
+// One shape per call, single-threaded like the reference: the host runs one call per core (bench.py, E2).
+#include "../../include/surfd_hip.h"
+#include "mc_luts.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <deque>
+#include <memory>
+#include <vector>
+
+namespace surfd {
+void set_error(const char *fmt, ...);
+}
+
+namespace {
+
+const double TINY = 2.220446049250313e-16;       // the reference's "FLT_EPSILON" is np.spacing(1.0) (pyx:35)
+
+struct Lut {
+    const signed char *v = nullptr;
+    int l1 = 1, l2 = 1;
+    int at(int a) const { return v[a]; }
+    int at(int a, int b) const { return v[a * l1 + b]; }
+    int at(int a, int b, int c) const { return v[a * l1 * l2 + b * l2 + c]; }
+};
+
+static Lut find_lut(const char *name) {
+    for (int i = 0; i < MC_LUT_COUNT; ++i)
+        if (!strcmp(MC_LUT_TABLE[i].name, name)) {
+            Lut l;
+            l.v = MC_LUT_TABLE[i].values;
+            l.l1 = MC_LUT_TABLE[i].ndim > 1 ? MC_LUT_TABLE[i].dims[1] : 1;
+            l.l2 = MC_LUT_TABLE[i].ndim > 2 ? MC_LUT_TABLE[i].dims[2] : 1;
+            return l;
+        }
+    return Lut();
+}
+
+struct Luts {
+    Lut ex, ey, ez, cases;
+    Lut t1, t2, t3_1, t3_2, t4_1, t4_2, t5, t6_1_1, t6_1_2, t6_2, t7_1, t7_2, t7_3, t7_4_1, t7_4_2, t8, t9;
+    Lut t10_1_1, t10_1_1_, t10_1_2, t10_2, t10_2_, t11, t12_1_1, t12_1_1_, t12_1_2, t12_2, t12_2_;
+    Lut t13_1, t13_1_, t13_2, t13_2_, t13_3, t13_3_, t13_4, t13_5_1, t13_5_2, t14;
+    Lut test3, test4, test6, test7, test10, test12, test13, sub13;
+    Luts() {
+        ex = find_lut("EDGESRELX"); ey = find_lut("EDGESRELY"); ez = find_lut("EDGESRELZ"); cases = find_lut("CASES");
+        t1 = find_lut("TILING1"); t2 = find_lut("TILING2"); t3_1 = find_lut("TILING3_1"); t3_2 = find_lut("TILING3_2");
+        t4_1 = find_lut("TILING4_1"); t4_2 = find_lut("TILING4_2"); t5 = find_lut("TILING5");
+        t6_1_1 = find_lut("TILING6_1_1"); t6_1_2 = find_lut("TILING6_1_2"); t6_2 = find_lut("TILING6_2");
+        t7_1 = find_lut("TILING7_1"); t7_2 = find_lut("TILING7_2"); t7_3 = find_lut("TILING7_3");
+        t7_4_1 = find_lut("TILING7_4_1"); t7_4_2 = find_lut("TILING7_4_2"); t8 = find_lut("TILING8"); t9 = find_lut("TILING9");
+        t10_1_1 = find_lut("TILING10_1_1"); t10_1_1_ = find_lut("TILING10_1_1_"); t10_1_2 = find_lut("TILING10_1_2");
+        t10_2 = find_lut("TILING10_2"); t10_2_ = find_lut("TILING10_2_"); t11 = find_lut("TILING11");
+        t12_1_1 = find_lut("TILING12_1_1"); t12_1_1_ = find_lut("TILING12_1_1_"); t12_1_2 = find_lut("TILING12_1_2");
+        t12_2 = find_lut("TILING12_2"); t12_2_ = find_lut("TILING12_2_");
+        t13_1 = find_lut("TILING13_1"); t13_1_ = find_lut("TILING13_1_"); t13_2 = find_lut("TILING13_2"); t13_2_ = find_lut("TILING13_2_");
+        t13_3 = find_lut("TILING13_3"); t13_3_ = find_lut("TILING13_3_"); t13_4 = find_lut("TILING13_4");
+        t13_5_1 = find_lut("TILING13_5_1"); t13_5_2 = find_lut("TILING13_5_2"); t14 = find_lut("TILING14");
+        test3 = find_lut("TEST3"); test4 = find_lut("TEST4"); test6 = find_lut("TEST6"); test7 = find_lut("TEST7");
+        test10 = find_lut("TEST10"); test12 = find_lut("TEST12"); test13 = find_lut("TEST13"); sub13 = find_lut("SUBCONFIG13");
+    }
+};
+
+static const Luts &luts() {
+    static const Luts L;
+    return L;
+}
+
+// edge -> vertex cache: 4 slots per voxel (3 owned edges + interior vertex), pages of 4096 voxels on first touch
+struct EdgeCache {
+    static const int LOG2 = 12;
+    std::vector<std::unique_ptr<int[]>> pages;
+    explicit EdgeCache(size_t voxels) : pages((voxels >> LOG2) + 1) {}
+    int get(size_t slot) const {
+        const std::unique_ptr<int[]> &p = pages[slot >> (LOG2 + 2)];
+        return p ? p[slot & ((size_t(4) << LOG2) - 1)] : -1;
+    }
+    void put(size_t slot, int v) {
+        std::unique_ptr<int[]> &p = pages[slot >> (LOG2 + 2)];
+        if (!p) {
+            p.reset(new int[size_t(4) << LOG2]);
+            for (size_t i = 0; i < (size_t(4) << LOG2); ++i) p[i] = -1;
+        }
+        p[slot & ((size_t(4) << LOG2) - 1)] = v;
+    }
+};
+
+struct Tiling { const Lut *lut; int sub; int nt; };      // sub < 0: two-index table
+
+static inline float sgn(float a) { return a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f); }
+static inline float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+}  // namespace
+
+struct surfd_mc {
+    int nx = 0, ny = 0, nz = 0, st = 1;
+    const float *im = nullptr, *gr = nullptr;
+    float *sign = nullptr;              // per-voxel sign (+1 / -1 / 0 = not set)
+    unsigned char *fixed = nullptr;     // sign is final (the voxel was a corner of a processed cube)
+    unsigned char *seen = nullptr;      // cube (by its low corner) is finished
+    std::unique_ptr<EdgeCache> cache;
+    // current cube
+    int cx = 0, cy = 0, cz = 0, pattern = 0;
+    double v[8];                        // signed corner values, marching-cubes corner order
+    double cv[8], cg[24], spread = 0.0; // corner values in xyz-bit order, corner gradients, max - min
+    bool centre_ready = false;
+    double centre[3] = {0, 0, 0}, centre_gx = 0.0, centre_gy = 0.0, centre_gz = 0.0;
+    float base_vec[3] = {0.f, 0.f, 0.f};
+    // result
+    std::vector<float> verts, normals, values;
+    std::vector<int> faces;
+
+    ~surfd_mc() { free(sign); free(fixed); free(seen); }
+
+    size_t vox(int z, int y, int x) const { return ((size_t)z * ny + y) * nx + x; }
+
+    // ---- Cell ------------------------------------------------------------------------------------------------
+    void set_cube(int x, int y, int z, const double (&val)[8]) {
+        cx = x; cy = y; cz = z;
+        pattern = 0;
+        for (int k = 0; k < 8; ++k) { v[k] = val[k]; if (v[k] > 0.0) pattern |= 1 << k; }
+        centre_ready = false;
+    }
+
+    void prepare() {
+        cv[0] = v[0]; cv[1] = v[1]; cv[2] = v[3]; cv[3] = v[2]; cv[4] = v[4]; cv[5] = v[5]; cv[6] = v[7]; cv[7] = v[6];
+        double lo = 0.0, hi = 0.0;
+        for (int i = 0; i < 8; ++i) { if (cv[i] > hi) hi = cv[i]; if (cv[i] < lo) lo = cv[i]; }
+        spread = hi - lo;
+        // one-sided differences along each axis, shared by the corners of an edge (pyx:795-802)
+        const double dx01 = v[0] - v[1], dx32 = v[3] - v[2], dx45 = v[4] - v[5], dx76 = v[7] - v[6];
+        const double dy03 = v[0] - v[3], dy12 = v[1] - v[2], dy47 = v[4] - v[7], dy56 = v[5] - v[6];
+        const double dz04 = v[0] - v[4], dz15 = v[1] - v[5], dz26 = v[2] - v[6], dz37 = v[3] - v[7];
+        const double g[8][3] = {{dx01, dy03, dz04}, {dx01, dy12, dz15}, {dx32, dy12, dz26}, {dx32, dy03, dz37},
+                                {dx45, dy47, dz04}, {dx45, dy56, dz15}, {dx76, dy56, dz26}, {dx76, dy47, dz37}};
+        for (int i = 0; i < 8; ++i) for (int c = 0; c < 3; ++c) cg[i * 3 + c] = g[i][c];
+    }
+
+    void centre_vertex() {
+        double w[8], fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0;
+        for (int k = 0; k < 8; ++k) w[k] = 1.0 / (TINY + fabs(v[k]));
+        static const double ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+        for (int k = 0; k < 8; ++k) { fx += ox[k] * w[k]; fy += oy[k] * w[k]; fz += oz[k] * w[k]; ff += w[k]; }
+        const double stp = (double)st;
+        centre[0] = cx + stp * fx / ff; centre[1] = cy + stp * fy / ff; centre[2] = cz + stp * fz / ff;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        sx = (w[0] * cg[0] + w[1] * cg[3] + w[2] * cg[6] + w[3] * cg[9] + w[4] * cg[12] + w[5] * cg[15] + w[6] * cg[18] + w[7] * cg[21]);
+        sy = (w[0] * cg[1] + w[1] * cg[4] + w[2] * cg[7] + w[3] * cg[10] + w[4] * cg[13] + w[5] * cg[16] + w[6] * cg[19] + w[7] * cg[22]);
+        sz = (w[0] * cg[2] + w[1] * cg[5] + w[2] * cg[8] + w[3] * cg[11] + w[4] * cg[14] + w[5] * cg[17] + w[6] * cg[20] + w[7] * cg[23]);
+        (void)sx;
+        // as the reference: the z-sum lands in the x slot and the z slot is never written (pyx:842-849)
+        centre_gx = sz; centre_gy = sy;
+        centre_ready = true;
+    }
+
+    size_t cache_slot(int e) const {
+        size_t i = vox(cz, cy, cx);
+        int j = 0;
+        if (e < 8) {
+            const bool upper = e >= 4;
+            const int h = upper ? e - 4 : e;
+            if (h == 1) { i += st; j = 1; }
+            else if (h == 2) i += (size_t)nx * st;
+            else if (h == 3) j = 1;
+            if (upper) i += (size_t)nx * ny;           // the reference adds ONE layer whatever the step (pyx:753-754)
+        } else if (e < 12) {
+            j = 2;
+            if (e == 9) i += st;
+            else if (e == 10) i += (size_t)nx * st + st;
+            else if (e == 11) i += (size_t)nx * st;
+        } else {
+            j = 3;
+        }
+        return 4 * i + j;
+    }
+
+    int new_vertex(float x, float y, float z) {
+        verts.push_back(x); verts.push_back(y); verts.push_back(z);
+        normals.push_back(0.f); normals.push_back(0.f); normals.push_back(0.f);
+        values.push_back(0.f);
+        return (int)values.size() - 1;
+    }
+    void add_normal(int vi, float gx, float gy, float gz) { normals[3 * vi] += gx; normals[3 * vi + 1] += gy; normals[3 * vi + 2] += gz; }
+    void add_corner_normal(int vi, int corner, float strength) {
+        add_normal(vi, (float)(cg[corner * 3] * strength), (float)(cg[corner * 3 + 1] * strength), (float)(cg[corner * 3 + 2] * strength));
+    }
+    void add_face(int vi) {
+        faces.push_back(vi);
+        if (spread > values[vi]) values[vi] = (float)spread;
+    }
+
+    void emit_edge(int e) {
+        const Luts &L = luts();
+        const size_t slot = cache_slot(e);
+        int vi = cache->get(slot);
+        if (e == 12) {
+            if (!centre_ready) centre_vertex();
+            if (vi < 0) { vi = new_vertex((float)centre[0], (float)centre[1], (float)centre[2]); cache->put(slot, vi); }
+            add_face(vi);
+            add_normal(vi, (float)centre_gx, (float)centre_gy, (float)centre_gz);
+            return;
+        }
+        const int dx1 = L.ex.at(e, 0), dx2 = L.ex.at(e, 1), dy1 = L.ey.at(e, 0), dy2 = L.ey.at(e, 1), dz1 = L.ez.at(e, 0), dz2 = L.ez.at(e, 1);
+        const int c1 = dz1 * 4 + dy1 * 2 + dx1, c2 = dz2 * 4 + dy2 * 2 + dx2;
+        const double w1 = 1.0 / (TINY + fabs(cv[c1])), w2 = 1.0 / (TINY + fabs(cv[c2]));
+        if (vi < 0) {
+            double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0;
+            fx += (double)dx1 * w1; fy += (double)dy1 * w1; fz += (double)dz1 * w1; ff += w1;
+            fx += (double)dx2 * w2; fy += (double)dy2 * w2; fz += (double)dz2 * w2; ff += w2;
+            const double stp = (double)st;
+            vi = new_vertex((float)((double)cx + stp * fx / ff), (float)((double)cy + stp * fy / ff), (float)((double)cz + stp * fz / ff));
+            cache->put(slot, vi);
+        }
+        add_face(vi);
+        add_corner_normal(vi, c1, (float)w1);
+        add_corner_normal(vi, c2, (float)w2);
+    }
+
+    // ---- Lewiner's disambiguation tests -------------------------------------------------------------------------
+    bool test_face(int face) const {
+        const int f = face < 0 ? -face : face;
+        double A = 0, B = 0, C = 0, D = 0;
+        switch (f) {
+            case 1: A = v[0]; B = v[4]; C = v[5]; D = v[1]; break;
+            case 2: A = v[1]; B = v[5]; C = v[6]; D = v[2]; break;
+            case 3: A = v[2]; B = v[6]; C = v[7]; D = v[3]; break;
+            case 4: A = v[3]; B = v[7]; C = v[4]; D = v[0]; break;
+            case 5: A = v[0]; B = v[3]; C = v[2]; D = v[1]; break;
+            case 6: A = v[4]; B = v[7]; C = v[6]; D = v[5]; break;
+            default: break;
+        }
+        const double q = A * C - B * D;
+        if (q > -TINY && q < TINY) return face >= 0;
+        return face * A * q >= 0;
+    }
+
+    bool test_interior(int mc_case, int config, int subconfig, int s) const {
+        const Luts &L = luts();
+        double t, At = 0.0, Bt = 0.0, Ct = 0.0, Dt = 0.0;
+        if (mc_case == 4 || mc_case == 10) {
+            const double a = (v[4] - v[0]) * (v[6] - v[2]) - (v[7] - v[3]) * (v[5] - v[1]);
+            const double b = v[2] * (v[4] - v[0]) + v[0] * (v[6] - v[2]) - v[1] * (v[7] - v[3]) - v[3] * (v[5] - v[1]);
+            t = -b / (2 * a + TINY);
+            if (t < 0 || t > 1) return s > 0;
+            At = v[0] + (v[4] - v[0]) * t; Bt = v[3] + (v[7] - v[3]) * t; Ct = v[2] + (v[6] - v[2]) * t; Dt = v[1] + (v[5] - v[1]) * t;
+        } else {
+            int edge = -1;
+            if (mc_case == 6) edge = L.test6.at(config, 2);
+            else if (mc_case == 7) edge = L.test7.at(config, 4);
+            else if (mc_case == 12) edge = L.test12.at(config, 3);
+            else if (mc_case == 13) edge = L.t13_5_1.at(config, subconfig, 0);
+            // per reference edge: the corner pair (p, q) that fixes t, then three (from, to) pairs for B, C, D
+            static const int P[12][8] = {{0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7}, {3, 0, 2, 1, 6, 5, 7, 4},
+                                         {4, 5, 7, 6, 3, 2, 0, 1}, {5, 6, 4, 7, 0, 3, 1, 2}, {6, 7, 5, 4, 1, 0, 2, 3}, {7, 4, 6, 5, 2, 1, 3, 0},
+                                         {0, 4, 3, 7, 2, 6, 1, 5}, {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
+            if (edge >= 0 && edge < 12) {
+                const int *p = P[edge];
+                t = v[p[0]] / (v[p[0]] - v[p[1]] + TINY);
+                At = 0;
+                Bt = v[p[2]] + (v[p[3]] - v[p[2]]) * t;
+                Ct = v[p[4]] + (v[p[5]] - v[p[4]]) * t;
+                Dt = v[p[6]] + (v[p[7]] - v[p[6]]) * t;
+            }
+        }
+        int test = 0;
+        if (At >= 0) test += 1;
+        if (Bt >= 0) test += 2;
+        if (Ct >= 0) test += 4;
+        if (Dt >= 0) test += 8;
+        switch (test) {
+            case 5: return (At * Ct - Bt * Dt < TINY) ? s > 0 : false;      // the reference falls off the end here: 0
+            case 10: return (At * Ct - Bt * Dt >= TINY) ? s > 0 : false;
+            case 7: case 11: case 13: case 14: case 15: return s < 0;
+            default: return s > 0;
+        }
+    }
+
+    // the case analysis: which triangle fan (table, sub-index, triangles) applies to the current cube
+    Tiling choose(int mc_case, int config) const {
+        const Luts &L = luts();
+        int sub = 0;
+        switch (mc_case) {
+            case 1: return {&L.t1, -1, 1};
+            case 2: return {&L.t2, -1, 2};
+            case 3: return test_face(L.test3.at(config)) ? Tiling{&L.t3_2, -1, 4} : Tiling{&L.t3_1, -1, 2};
+            case 4: return test_interior(4, config, 0, L.test4.at(config)) ? Tiling{&L.t4_1, -1, 2} : Tiling{&L.t4_2, -1, 6};
+            case 5: return {&L.t5, -1, 3};
+            case 6:
+                if (test_face(L.test6.at(config, 0))) return {&L.t6_2, -1, 5};
+                return test_interior(6, config, 0, L.test6.at(config, 1)) ? Tiling{&L.t6_1_1, -1, 3} : Tiling{&L.t6_1_2, -1, 9};
+            case 7:
+                if (test_face(L.test7.at(config, 0))) sub += 1;
+                if (test_face(L.test7.at(config, 1))) sub += 2;
+                if (test_face(L.test7.at(config, 2))) sub += 4;
+                switch (sub) {
+                    case 0: return {&L.t7_1, -1, 3};
+                    case 1: return {&L.t7_2, 0, 5};
+                    case 2: return {&L.t7_2, 1, 5};
+                    case 3: return {&L.t7_3, 0, 9};
+                    case 4: return {&L.t7_2, 2, 5};
+                    case 5: return {&L.t7_3, 1, 9};
+                    case 6: return {&L.t7_3, 2, 9};
+                    default: return test_interior(7, config, 7, L.test7.at(config, 3)) ? Tiling{&L.t7_4_2, -1, 9} : Tiling{&L.t7_4_1, -1, 5};
+                }
+            case 8: return {&L.t8, -1, 2};
+            case 9: return {&L.t9, -1, 4};
+            case 10: {
+                const bool f0 = test_face(L.test10.at(config, 0));
+                const bool f1 = test_face(L.test10.at(config, 1));     // (the reference evaluates it on both branches)
+                if (f0) return f1 ? Tiling{&L.t10_1_1_, -1, 4} : Tiling{&L.t10_2, -1, 8};
+                if (f1) return {&L.t10_2_, -1, 8};
+                return test_interior(10, config, 0, L.test10.at(config, 2)) ? Tiling{&L.t10_1_1, -1, 4} : Tiling{&L.t10_1_2, -1, 8};
+            }
+            case 11: return {&L.t11, -1, 4};
+            case 12: {
+                const bool f0 = test_face(L.test12.at(config, 0));
+                const bool f1 = test_face(L.test12.at(config, 1));
+                if (f0) return f1 ? Tiling{&L.t12_1_1_, -1, 4} : Tiling{&L.t12_2, -1, 8};
+                if (f1) return {&L.t12_2_, -1, 8};
+                return test_interior(12, config, 0, L.test12.at(config, 2)) ? Tiling{&L.t12_1_1, -1, 4} : Tiling{&L.t12_1_2, -1, 8};
+            }
+            case 13: {
+                for (int k = 0; k < 6; ++k)
+                    if (test_face(L.test13.at(config, k))) sub += 1 << k;
+                sub = L.sub13.at(sub);
+                if (sub == 0) return {&L.t13_1, -1, 4};
+                if (sub <= 6) return {&L.t13_2, sub - 1, 6};
+                if (sub <= 18) return {&L.t13_3, sub - 7, 10};
+                if (sub <= 22) return {&L.t13_4, sub - 19, 12};
+                if (sub <= 26) {
+                    const int k = sub - 23;
+                    return test_interior(13, config, k, L.test13.at(config, 6)) ? Tiling{&L.t13_5_1, k, 6} : Tiling{&L.t13_5_2, k, 10};
+                }
+                if (sub <= 38) return {&L.t13_3_, sub - 27, 10};
+                if (sub <= 44) return {&L.t13_2_, sub - 39, 6};
+                if (sub == 45) return {&L.t13_1_, -1, 4};
+                return {nullptr, -1, 0};
+            }
+            case 14: return {&L.t14, -1, 4};
+            default: return {nullptr, -1, 0};
+        }
+    }
+
+    static int fan_edge(const Tiling &t, int config, int k) { return t.sub < 0 ? t.lut->at(config, k) : t.lut->at(config, t.sub, k); }
+
+    // how many distinct, already existing vertices the fan of the current cube would reuse (check_triangles, pyx:467-525)
+    int shared_vertices(int mc_case, int config) {
+        const Tiling t = choose(mc_case, config);
+        if (!t.lut) return 0;
+        prepare();
+        int found[40], nfound = 0, hits = 0;
+        for (int k = 0; k < 3 * t.nt; ++k) {
+            const int vi = cache->get(cache_slot(fan_edge(t, config, k)));
+            bool dup = false;
+            for (int i = 0; i < nfound; ++i) dup |= found[i] == vi;
+            if (!dup && vi >= 0) ++hits;
+            found[nfound++] = vi;
+        }
+        return hits;
+    }
+
+    void triangulate(int mc_case, int config) {
+        const Tiling t = choose(mc_case, config);
+        if (!t.lut) return;
+        prepare();
+        for (int k = 0; k < 3 * t.nt; ++k) emit_edge(fan_edge(t, config, k));
+    }
+
+    // ---- sign voting ------------------------------------------------------------------------------------------------
+    static float edge_vote(const float *g1, const float *g2, int dz, int dy, int dx) {
+        const float dir_sum = (float)dz + (float)dy + (float)dx;
+        const int c = dz != 0 ? 0 : (dy != 0 ? 1 : 2);
+        const float p1 = g1[c], p2 = g2[c];
+        if (dir_sum > 0) return (p2 > 0 && p1 < 0) ? 1.0f : dot3(g1, g2);
+        return (p2 < 0 && p1 > 0) ? 1.0f : dot3(g1, g2);
+    }
+
+    int run();
+    int run_iso(double level, bool classic);
+};
+
+int surfd_mc::run() {
+    const Luts &L = luts();
+    const int s = st;
+    const int xb = nx - 2 * s, yb = ny - 2 * s, zb = nz - 2 * s;
+    const double voxel = 2.0 / (nx - 1);
+    const float avg_thr = (float)(1.05 * voxel), max_thr = (float)(1.74 * voxel);
+    const double unsure_thr = (double)0.707f;
+    const int dirs[6][3] = {{s, 0, 0}, {-s, 0, 0}, {0, s, 0}, {0, -s, 0}, {0, 0, s}, {0, 0, -s}};
+    struct Cube { int z, y, x; };
+    std::deque<Cube> queue, unsure, hard;
+
+    auto near_surface = [&](int z, int y, int x) {
+        const float a = im[vox(z, y, x)], b = im[vox(z, y, x + s)], c = im[vox(z, y + s, x + s)], d = im[vox(z, y + s, x)];
+        const float e = im[vox(z + s, y, x)], f = im[vox(z + s, y, x + s)], g = im[vox(z + s, y + s, x + s)], h = im[vox(z + s, y + s, x)];
+        const float avg = 0.125f * (a + b + c + d + e + f + g + h);
+        const float mx = fmaxf(a, fmaxf(b, fmaxf(c, fmaxf(d, fmaxf(e, fmaxf(f, fmaxf(g, h)))))));
+        return avg < avg_thr && mx <= max_thr;
+    };
+    auto push_neighbours = [&](int z, int y, int x) {
+        if (x + s < xb) queue.push_back({z, y, x + s});
+        if (y + s < yb) queue.push_back({z, y + s, x});
+        if (x - s >= 0) queue.push_back({z, y, x - s});
+        if (y - s >= 0) queue.push_back({z, y - s, x});
+        if (z - s >= 0) queue.push_back({z - s, y, x});
+        if (z + s < zb) queue.push_back({z + s, y, x});
+    };
+
+    // One cube.  grow = false: seed found by the raster scan; true: reached by the breadth-first growth.
+    // Returns true when the cube produced triangles (a seed then starts the growth).
+    bool probing = false;             // growth only: the neighbours of an unsure cube are being pre-voted
+    auto process = [&](int z, int y, int x, bool grow) -> bool {
+        if (seen[vox(z, y, x)] || !near_surface(z, y, x)) return false;
+        const int cz_[8] = {z, z, z, z, z + s, z + s, z + s, z + s};
+        const int cy_[8] = {y, y, y + s, y + s, y, y, y + s, y + s};
+        const int cx_[8] = {x, x + s, x + s, x, x, x + s, x + s, x};
+        int votes[8];
+        float tally[8];
+        for (int k = 0; k < 8; ++k) {
+            votes[k] = 0; tally[k] = 0.f;
+            const size_t p = vox(cz_[k], cy_[k], cx_[k]);
+            if (fixed[p]) { votes[k] = 1; tally[k] = sign[p]; continue; }
+            if (im[p] == 0.0f) { votes[k] = 1; continue; }
+            for (int d = 0; d < 6; ++d) {
+                int i = 0, reach = 1;
+                while (i < reach) {
+                    ++i;
+                    const int qz = cz_[k] + i * dirs[d][0], qy = cy_[k] + i * dirs[d][1], qx = cx_[k] + i * dirs[d][2];
+                    if (qz > zb || qz < 0 || qy > yb || qy < 0 || qx > xb || qx < 0) break;
+                    const size_t q = vox(qz, qy, qx);
+                    if (im[q] == 0.0f) { if (i >= reach) ++reach; continue; }      // look past exact zeros
+                    if (sign[q] == 0.0f) continue;
+                    ++votes[k];
+                    tally[k] += sign[q] * edge_vote(gr + 3 * p, gr + 3 * q, dirs[d][0], dirs[d][1], dirs[d][2]);
+                }
+            }
+            if (grow && votes[k] >= 1 && (double)fabsf(tally[k]) / (double)votes[k] < unsure_thr && !queue.empty()) {
+                if (!probing) unsure.push_back({z, y, x});
+                return false;
+            }
+            sign[p] = sgn(tally[k]);           // provisional: usable by later votes, recomputed until the cube is processed
+        }
+        bool all_voted = true;
+        for (int k = 0; k < 8; ++k) all_voted &= votes[k] >= 1;
+        if (!all_voted) {
+            // corners nobody voted for follow an anchor: the first fixed corner with a gradient (its sign applied),
+            // else the first corner with a gradient; visiting order as the reference (pyx:1319-1353)
+            static const int order[8] = {0, 1, 3, 2, 4, 5, 7, 6};
+            float anchor_sign = 1.f;
+            int pick = -1;
+            for (int o = 0; o < 8 && pick < 0; ++o) {
+                const size_t p = vox(cz_[order[o]], cy_[order[o]], cx_[order[o]]);
+                const float *g = gr + 3 * p;
+                if (fixed[p] && (fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2])) > 0) { pick = order[o]; anchor_sign = sgn(sign[p]); }
+            }
+            for (int o = 0; o < 8 && pick < 0; ++o) {
+                const float *g = gr + 3 * vox(cz_[order[o]], cy_[order[o]], cx_[order[o]]);
+                if ((fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2])) > 0) pick = order[o];
+            }
+            if (pick >= 0) {
+                const float *g = gr + 3 * vox(cz_[pick], cy_[pick], cx_[pick]);
+                base_vec[0] = g[0]; base_vec[1] = g[1]; base_vec[2] = g[2];
+            }
+            base_vec[0] = anchor_sign * base_vec[0]; base_vec[1] = anchor_sign * base_vec[1]; base_vec[2] = anchor_sign * base_vec[2];
+            const bool cautious = grow && !probing && !queue.empty();
+            for (int k = 0; k < 8; ++k) {
+                if (votes[k] != 0) continue;
+                const size_t p = vox(cz_[k], cy_[k], cx_[k]);
+                const float dp = dot3(base_vec, gr + 3 * p);
+                if (cautious && (double)fabsf(dp) < unsure_thr) { unsure.push_back({z, y, x}); return false; }
+                sign[p] = sgn(dp);
+            }
+        }
+        if (grow && probing) return false;          // pre-vote only: no triangles, not finished
+        double val[8];
+        for (int k = 0; k < 8; ++k) {
+            const size_t p = vox(cz_[k], cy_[k], cx_[k]);
+            val[k] = (double)(sign[p] * im[p]);
+        }
+        set_cube(x, y, z, val);
+        for (int k = 0; k < 8; ++k) fixed[vox(cz_[k], cy_[k], cx_[k])] = 1;
+        const int mc_case = L.cases.at(pattern, 0);
+        if (mc_case <= 0) { seen[vox(z, y, x)] = 1; return false; }
+        if (grow) {
+            const bool simple = mc_case == 1 || mc_case == 2 || mc_case == 5 || mc_case == 8 || mc_case == 9;
+            if (!simple && (!queue.empty() || !unsure.empty())) { hard.push_back({z, y, x}); return false; }
+        }
+        const int config = L.cases.at(pattern, 1);
+        if (grow && shared_vertices(mc_case, config) < 2) return false;     // must hang on the existing surface
+        seen[vox(z, y, x)] = 1;
+        triangulate(mc_case, config);
+        push_neighbours(z, y, x);
+        return true;
+    };
+
+    // scan positions 0, s, 2s, ... up to and including the first one >= bound (the reference's while-loops, pyx:1196-1206)
+    for (int zi = 0;; zi += s) {
+      for (int yi = 0;; yi += s) {
+        for (int xi = 0;; xi += s) {
+            if (process(zi, yi, xi, false)) {
+                probing = false;
+                while (!queue.empty() || !unsure.empty() || !hard.empty()) {
+                    Cube c;
+                    if (!queue.empty()) { c = queue.front(); queue.pop_front(); }
+                    else if (!unsure.empty()) {
+                        c = unsure.front();
+                        if (!probing) {
+                            // first give the neighbours of an unsure cube a (provisional) vote, then retry the cube itself
+                            if (seen[vox(c.z, c.y, c.x)]) { unsure.pop_front(); continue; }
+                            push_neighbours(c.z, c.y, c.x);
+                            probing = true;
+                            continue;
+                        }
+                        unsure.pop_front();
+                        probing = false;
+                    } else { c = hard.front(); hard.pop_front(); }
+                    process(c.z, c.y, c.x, true);
+                }
+            }
+            if (xi >= xb) break;
+        }
+        if (yi >= yb) break;
+      }
+      if (zi >= zb) break;
+    }
+    return 0;
+}
+
+// Plain level-set marching cubes over every cube (the watertight path of the reference scripts, SURVEY.md §8 f3:
+// sample/generate_text.py:132-158 extracts the 0.01 level of the UDF with PyMCubes).  classic = true uses the
+// original 256-entry triangle table (what PyMCubes implements), false Lewiner's disambiguated cases; vertices are
+// linear interpolants on the cube edges, shared between neighbouring cubes through the same edge cache.
+int surfd_mc::run_iso(double level, bool classic) {
+    const Luts &L = luts();
+    static const Lut classic_lut = find_lut("CASESCLASSIC");
+    const int s = st, xb = nx - 2 * s, yb = ny - 2 * s, zb = nz - 2 * s;
+    for (int z = 0;; z += s) {
+      for (int y = 0;; y += s) {
+        for (int x = 0;; x += s) {
+            const double val[8] = {im[vox(z, y, x)] - level, im[vox(z, y, x + s)] - level, im[vox(z, y + s, x + s)] - level, im[vox(z, y + s, x)] - level,
+                                   im[vox(z + s, y, x)] - level, im[vox(z + s, y, x + s)] - level, im[vox(z + s, y + s, x + s)] - level, im[vox(z + s, y + s, x)] - level};
+            set_cube(x, y, z, val);
+            if (pattern != 0 && pattern != 255) {
+                if (classic) {
+                    int nt = 0;
+                    while (nt < 5 && classic_lut.at(pattern, 3 * nt) != -1) ++nt;
+                    if (nt > 0) {
+                        prepare();
+                        for (int k = 0; k < 3 * nt; ++k) emit_edge(classic_lut.at(pattern, k));
+                    }
+                } else {
+                    const int mc_case = L.cases.at(pattern, 0);
+                    if (mc_case > 0) triangulate(mc_case, L.cases.at(pattern, 1));
+                }
+            }
+            if (x >= xb) break;
+        }
+        if (y >= yb) break;
+      }
+      if (z >= zb) break;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int surfd_mc_iso(const float *volume, int nz, int ny, int nx, double level, int classic, int step, surfd_mc **out) {
+    if (!volume || !out) { surfd::set_error("surfd_mc_iso: null argument"); return SURFD_ERR_ARG; }
+    if (nx < 2 || ny < 2 || nz < 2 || step < 1) { surfd::set_error("surfd_mc_iso: volume must be at least 2x2x2 and step >= 1"); return SURFD_ERR_ARG; }
+    std::unique_ptr<surfd_mc> m(new surfd_mc());
+    m->nx = nx; m->ny = ny; m->nz = nz; m->st = step; m->im = volume;
+    m->cache.reset(new EdgeCache((size_t)nx * ny * nz));
+    m->run_iso(level, classic != 0);
+    m->im = nullptr;
+    *out = m.release();
+    return SURFD_OK;
+}
+
+int surfd_mc_udf(const float *udf, const float *grads, int nz, int ny, int nx, int step, surfd_mc **out) {
+    if (!udf || !grads || !out) { surfd::set_error("surfd_mc_udf: null argument"); return SURFD_ERR_ARG; }
+    if (nx < 2 || ny < 2 || nz < 2 || step < 1) { surfd::set_error("surfd_mc_udf: volume must be at least 2x2x2 and step >= 1"); return SURFD_ERR_ARG; }
+    std::unique_ptr<surfd_mc> m(new surfd_mc());
+    m->nx = nx; m->ny = ny; m->nz = nz; m->st = step; m->im = udf; m->gr = grads;
+    const size_t n = (size_t)nx * ny * nz;
+    m->sign = (float *)calloc(n, sizeof(float));
+    m->fixed = (unsigned char *)calloc(n, 1);
+    m->seen = (unsigned char *)calloc(n, 1);
+    if (!m->sign || !m->fixed || !m->seen) { surfd::set_error("surfd_mc_udf: out of memory (%zu voxels)", n); return SURFD_ERR_STATE; }
+    m->cache.reset(new EdgeCache(n));
+    m->run();
+    m->im = m->gr = nullptr;
+    *out = m.release();
+    return SURFD_OK;
+}
+
+int64_t surfd_mc_num_vertices(const surfd_mc *m) { return m ? (int64_t)m->values.size() : 0; }
+int64_t surfd_mc_num_faces(const surfd_mc *m) { return m ? (int64_t)m->faces.size() / 3 : 0; }
+
+int surfd_mc_copy(const surfd_mc *m, float *vertices, int32_t *faces, float *normals, float *values) {
+    if (!m) { surfd::set_error("surfd_mc_copy: null handle"); return SURFD_ERR_ARG; }
+    const size_t nv = m->values.size();
+    // the reference hands out vertices / normals in (z, y, x) column order and reverses every triangle
+    // (_marching_cubes_lewiner.py:133-142, gradient_direction="descent")
+    if (vertices)
+        for (size_t i = 0; i < nv; ++i) { vertices[3 * i] = m->verts[3 * i + 2]; vertices[3 * i + 1] = m->verts[3 * i + 1]; vertices[3 * i + 2] = m->verts[3 * i]; }
+    if (normals)
+        for (size_t i = 0; i < nv; ++i) {
+            double len = 0.0;
+            for (int c = 0; c < 3; ++c) { const double d = m->normals[3 * i + c]; len += d * d; }
+            if (len > 0.0) len = 1.0 / sqrt(len);
+            for (int c = 0; c < 3; ++c) normals[3 * i + c] = (float)(m->normals[3 * i + 2 - c] * len);
+        }
+    if (values) memcpy(values, m->values.data(), nv * sizeof(float));
+    if (faces)
+        for (size_t f = 0; f + 2 < m->faces.size(); f += 3) { faces[f] = m->faces[f + 2]; faces[f + 1] = m->faces[f + 1]; faces[f + 2] = m->faces[f]; }
+    return SURFD_OK;
+}
+
+void surfd_mc_destroy(surfd_mc *m) { delete m; }
+
+// the case tables themselves (tests drive the reference's own extension with them on hosts without the reference tree)
+int surfd_mc_lut_count(void) { return MC_LUT_COUNT; }
+int surfd_mc_lut(int i, const char **name, const signed char **values, int *ndim, int dims[3]) {
+    if (i < 0 || i >= MC_LUT_COUNT || !name || !values || !ndim || !dims) { surfd::set_error("surfd_mc_lut: bad argument"); return SURFD_ERR_ARG; }
+    *name = MC_LUT_TABLE[i].name; *values = MC_LUT_TABLE[i].values; *ndim = MC_LUT_TABLE[i].ndim;
+    for (int k = 0; k < 3; ++k) dims[k] = MC_LUT_TABLE[i].dims[k];
+    return SURFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+"""Mesh post-processing of get_mesh_from_udf (reference meshudf/meshudf.py:349-437) without trimesh — SURVEY.md §8 f2.
+
+The reference leans on trimesh 4.0.8 for every step after marching cubes.  trimesh is not installed here (and has no
+place in a from-scratch path), so the operations the script actually reaches are restated in numpy, one function per
+trimesh call, each naming the trimesh routine whose documented behaviour it follows:
+
+  edges_of_faces            Trimesh.edges / edges_face          (faces_to_edges: (a,b),(b,c),(c,a) per face, face-major)
+  cull_and_merge            Trimesh.process(validate=False)      (drop unreferenced vertices, merge vertices equal to
+                                                                  1e-8, first-occurrence order kept)
+  drop_duplicate_faces      Trimesh.remove_duplicate_faces       (same vertex set = same face; survivors in the order of
+                                                                  np.unique over the sorted rows, as trimesh applies it)
+  drop_degenerate_faces     Trimesh.remove_degenerate_faces      (both oriented-box heights of the triangle > 1e-8)
+  fill_small_holes          Trimesh.fill_holes                   (3- and 4-edge boundary loops closed, winding opposed
+                                                                  to the neighbouring face)
+  border_edge_rows          grouping.group_rows(edges_sorted, require_count=1)
+  smooth_borders            the Laplacian loop of meshudf.py:408-434
+  vertex_normals_by_angle   geometry.weighted_vertex_normals     (differentiable branch, meshudf.py:440-446)
+
+PARITY NOTE: no trimesh exists in the build container or on the GPU box, so these restatements are pinned by
+hand-checkable fixtures (tests/test_meshproc_cpu.py), NOT by trimesh outputs — "parity unpinned vs trimesh".  Where
+trimesh's result depends on an implementation detail (the order np.unique gives faces, networkx's cycle order in
+fill_holes) the SET of vertices / faces is the contract here and the order is documented as ours.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+MERGE_TOL = 1e-8          # trimesh.constants.tol.merge
+
+
+def edges_of_faces(faces: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(edges[3F,2], edge_face[3F]): the three directed edges of every face in face order."""
+    faces = np.asarray(faces)
+    edges = faces[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2)
+    return edges, np.repeat(np.arange(len(faces)), 3)
+
+
+def _pack_rows(rows: np.ndarray) -> np.ndarray:
+    """Rows of up to 4 non-negative ints -> one sortable key per row, the LAST column most significant (the order
+    trimesh's hashable_rows produces for small integer arrays)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    if rows.size == 0:
+        return np.zeros(0, dtype=np.uint64)
+    bits = 64 // rows.shape[1]
+    if rows.max() >= (1 << (bits - 1)) - 1:
+        # too wide to pack: order lexicographically from the last column instead (same order, no bit tricks)
+        order = np.lexsort([rows[:, c] for c in range(rows.shape[1])])
+        key = np.empty(len(rows), dtype=np.uint64)
+        key[order] = np.arange(len(rows), dtype=np.uint64)
+        # equal rows must share a key
+        srt = rows[order]
+        same = np.concatenate([[False], (srt[1:] == srt[:-1]).all(axis=1)])
+        ranks = np.cumsum(~same) - 1
+        key[order] = ranks.astype(np.uint64)
+        return key
+    key = np.zeros(len(rows), dtype=np.uint64)
+    for c in range(rows.shape[1]):
+        key ^= (rows[:, c].astype(np.uint64) + np.uint64(1)) << np.uint64(c * bits)
+    return key
+
+
+def cull_and_merge(vertices: np.ndarray, faces: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Vertices nobody references disappear; vertices whose coordinates agree after rounding to 8 decimals become one;
+    survivors keep the order of their first occurrence; faces are re-indexed.  Non-finite vertices (and their faces) go."""
+    vertices = np.asarray(vertices, dtype=np.float64)
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(vertices) == 0 or len(faces) == 0:
+        return vertices[:0].reshape(0, 3), faces[:0]
+    finite = np.isfinite(vertices).all(axis=1)
+    if not finite.all():
+        faces = faces[finite[faces].all(axis=1)]
+    referenced = np.zeros(len(vertices), dtype=bool)
+    referenced[faces] = True
+    referenced &= finite
+    quant = np.round(np.where(finite[:, None], vertices, 0.0) * (1.0 / MERGE_TOL)).astype(np.int64)
+    ref_idx = np.nonzero(referenced)[0]
+    _, first, inv = np.unique(quant[ref_idx], axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")                  # unique rows in order of first occurrence
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    new_index = np.zeros(len(vertices), dtype=np.int64)
+    new_index[ref_idx] = rank[inv.reshape(-1)]
+    return vertices[ref_idx[first[order]]], new_index[faces]
+
+
+def drop_duplicate_faces(faces: np.ndarray) -> np.ndarray:
+    """One face per vertex triple (winding ignored).  Survivors are the first occurrences, listed in the order of the
+    sorted keys (max index most significant) — trimesh re-orders the face array this way, and later steps see it."""
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(faces) == 0:
+        return faces
+    _, first = np.unique(_pack_rows(np.sort(faces, axis=1)), return_index=True)
+    return faces[first]
+
+
+def drop_degenerate_faces(vertices: np.ndarray, faces: np.ndarray, height: float = MERGE_TOL) -> np.ndarray:
+    """Keeps triangles whose two heights over the edges leaving vertex 0 both exceed `height`."""
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(faces) == 0:
+        return faces
+    tri = np.asarray(vertices, dtype=np.float64)[faces]
+    a, b = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    area = np.sqrt((np.cross(a, b) ** 2).sum(axis=1)) * 0.5
+    la, lb = np.sqrt((a ** 2).sum(axis=1)), np.sqrt((b ** 2).sum(axis=1))
+    box = np.zeros((len(faces), 2))
+    oka, okb = la > MERGE_TOL, lb > MERGE_TOL
+    box[oka, 0] = 2.0 * area[oka] / la[oka]
+    box[okb, 1] = 2.0 * area[okb] / lb[okb]
+    return faces[(box > height).all(axis=1)]
+
+
+def border_edge_rows(faces: np.ndarray) -> np.ndarray:
+    """Rows of edges_of_faces(faces) whose undirected edge occurs exactly once, ordered by the edge's (larger vertex,
+    smaller vertex)."""
+    edges, _ = edges_of_faces(faces)
+    key = _pack_rows(np.sort(edges, axis=1))
+    order = np.argsort(key, kind="stable")
+    srt = key[order]
+    start = np.concatenate([[True], srt[1:] != srt[:-1]])
+    idx = np.nonzero(start)[0]
+    count = np.diff(np.concatenate([idx, [len(srt)]]))
+    return order[idx[count == 1]]
+
+
+def fill_small_holes(vertices: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """Closes holes bounded by exactly 3 or 4 border edges (one missing triangle / one missing quad, the latter as two
+    triangles sharing the diagonal 2-0 of the loop), with the winding that opposes the face across the loop's first edge.
+    Larger holes stay open.  New faces are appended in ascending order of their smallest vertex."""
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(faces) < 3:
+        return faces
+    rows = border_edge_rows(faces)
+    if len(rows) < 3:
+        return faces
+    edges, _ = edges_of_faces(faces)
+    bedges = edges[rows]                                   # directed as in their (only) face
+    nxt = {}
+    ambiguous = set()
+    for u, v in bedges:
+        if u in nxt:
+            ambiguous.add(u)                               # a vertex with two outgoing border edges: not a simple loop
+        nxt[int(u)] = int(v)
+    used, loops = set(), []
+    for u0 in sorted(nxt):
+        if u0 in used or u0 in ambiguous:
+            continue
+        loop, u = [u0], nxt[u0]
+        while u != u0 and u in nxt and u not in used and u not in ambiguous and len(loop) <= 4:
+            loop.append(u)
+            u = nxt[u]
+        if u == u0 and len(loop) in (3, 4):
+            loops.append(loop)
+            used.update(loop)
+    new = []
+    for loop in loops:
+        # border edges run WITH their face's winding, so the cap must run against them
+        r = loop[::-1]
+        if len(r) == 3:
+            new.append(r)
+        else:
+            new.append([r[0], r[1], r[2]])
+            new.append([r[2], r[3], r[0]])
+    if not new:
+        return faces
+    new = np.array(new, dtype=np.int64)
+    return np.vstack([faces, new[np.argsort(new.min(axis=1), kind="stable")]])
+
+
+def smooth_borders(vertices: np.ndarray, faces: np.ndarray, lam: float = 0.3, iterations: int = 20) -> np.ndarray:
+    """Jacobi Laplacian smoothing of the BORDER polyline only (meshudf.py:408-434): every vertex on an edge that belongs
+    to a single face moves 0.3 of the way to the mean of its border neighbours, 20 times; interior vertices stay."""
+    vertices = np.array(vertices, dtype=np.float64, copy=True)
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    rows = border_edge_rows(faces)
+    if len(rows) == 0:
+        return vertices
+    edges, _ = edges_of_faces(faces)
+    be = np.sort(edges[rows], axis=1)
+    src = np.concatenate([be[:, 0], be[:, 1]])
+    dst = np.concatenate([be[:, 1], be[:, 0]])
+    border = np.unique(src)
+    deg = np.bincount(src, minlength=len(vertices)).astype(np.float64)
+    for _ in range(iterations):
+        acc = np.zeros_like(vertices)
+        np.add.at(acc, src, vertices[dst])
+        mean = acc[border] / deg[border, None]
+        vertices[border] = vertices[border] + lam * (mean - vertices[border])
+    return vertices
+
+
+def vertex_normals_by_angle(vertices: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """Unit vertex normals as the corner-angle weighted sum of the unit face normals (weighted_vertex_normals)."""
+    vertices = np.asarray(vertices, dtype=np.float64)
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    tri = vertices[faces]
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    ln = np.linalg.norm(fn, axis=1, keepdims=True)
+    fn = np.divide(fn, ln, out=np.zeros_like(fn), where=ln > 0)
+    out = np.zeros_like(vertices)
+    for c in range(3):
+        a = tri[:, (c + 1) % 3] - tri[:, c]
+        b = tri[:, (c + 2) % 3] - tri[:, c]
+        cosang = (a * b).sum(axis=1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-300)
+        ang = np.arccos(np.clip(cosang, -1.0, 1.0))
+        np.add.at(out, faces[:, c], fn * ang[:, None])
+    ln = np.linalg.norm(out, axis=1, keepdims=True)
+    return np.divide(out, ln, out=np.zeros_like(out), where=ln > 0)
+
+
+def clean_until_stable(vertices: np.ndarray, faces: np.ndarray, max_iter: int = 10) -> Tuple[np.ndarray, np.ndarray]:
+    """meshudf.py:380-404: process + duplicate / degenerate removal + single-hole filling once, then the same cleaning
+    (without hole filling) repeated until vertex and face counts stop changing (at most 10 rounds)."""
+    v, f = cull_and_merge(vertices, faces)
+    f = drop_duplicate_faces(f)
+    f = drop_degenerate_faces(v, f)
+    f = fill_small_holes(v, f)
+    v, f = cull_and_merge(v, f)                     # Trimesh(mesh.vertices, mesh.faces) re-processes on construction
+    counts, rounds = (0, 0), 0
+    while counts != (len(v), len(f)) and rounds < max_iter:
+        v, f = cull_and_merge(v, f)
+        f = drop_duplicate_faces(f)
+        f = drop_degenerate_faces(v, f)
+        counts = (len(v), len(f))
+        rounds += 1
+        v, f = cull_and_merge(v, f)
+    return v, f
+
+
+def face_components(faces: np.ndarray, n_vertices: int) -> np.ndarray:
+    """Label per face: faces that share a vertex are connected (Trimesh.split / MeshLab's connected components)."""
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    parent = np.arange(n_vertices, dtype=np.int64)
+
+    def find(a):
+        # pointer jumping on arrays: O(log n) sweeps
+        while True:
+            nxt = parent[a]
+            if (nxt == a).all():
+                return a
+            parent[a] = parent[nxt]
+            a = parent[a]
+    for _ in range(64):
+        ra, rb, rc = find(faces[:, 0]), find(faces[:, 1]), find(faces[:, 2])
+        lo = np.minimum(np.minimum(ra, rb), rc)
+        if (ra == lo).all() and (rb == lo).all() and (rc == lo).all():
+            break
+        np.minimum.at(parent, ra, lo); np.minimum.at(parent, rb, lo); np.minimum.at(parent, rc, lo)
+    roots = find(faces[:, 0])
+    _, labels = np.unique(roots, return_inverse=True)
+    return labels.reshape(-1)
+
+
+def keep_components_with_at_least(vertices: np.ndarray, faces: np.ndarray, min_faces: int) -> Tuple[np.ndarray, np.ndarray]:
+    """meshing_remove_connected_component_by_face_number(mincomponentsize=...): components with fewer faces go, and the
+    vertices only they used with them."""
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(faces) == 0:
+        return np.asarray(vertices, dtype=np.float64), faces
+    labels = face_components(faces, len(vertices))
+    sizes = np.bincount(labels)
+    kept = faces[sizes[labels] >= min_faces]
+    used = np.zeros(len(vertices), dtype=bool)
+    used[kept] = True
+    remap = np.cumsum(used) - 1
+    return np.asarray(vertices, dtype=np.float64)[used], remap[kept]
+
+
+def laplacian_smooth(vertices: np.ndarray, faces: np.ndarray, steps: int = 3) -> np.ndarray:
+    """Umbrella (uniform-weight) Laplacian smoothing of every vertex, `steps` Jacobi sweeps: each vertex moves to the
+    mean of its edge neighbours.  Stands in for MeshLab's apply_coord_laplacian_smoothing (3 steps by default;
+    MeshLab's default weighting is cotangent — package absent here, parity unpinned)."""
+    vertices = np.array(vertices, dtype=np.float64, copy=True)
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(faces) == 0:
+        return vertices
+    e, _ = edges_of_faces(faces)
+    und = np.unique(np.sort(e, axis=1), axis=0)
+    src = np.concatenate([und[:, 0], und[:, 1]])
+    dst = np.concatenate([und[:, 1], und[:, 0]])
+    deg = np.bincount(src, minlength=len(vertices)).astype(np.float64)
+    has = deg > 0
+    for _ in range(steps):
+        acc = np.zeros_like(vertices)
+        np.add.at(acc, src, vertices[dst])
+        vertices[has] = acc[has] / deg[has, None]
+    return vertices
+
+
+def write_obj(path: str, vertices: np.ndarray, faces: np.ndarray) -> None:
+    """Wavefront OBJ: `v x y z` lines, then 1-based `f a b c` lines (what o3d.io.write_triangle_mesh emits for a bare mesh)."""
+    import os
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as fh:
+        fh.write("# surfd_amd mesh\n")
+        for x, y, z in np.asarray(vertices, dtype=np.float64):
+            fh.write(f"v {x:.6f} {y:.6f} {z:.6f}\n")
+        for a, b, c in np.asarray(faces, dtype=np.int64) + 1:
+            fh.write(f"f {a} {b} {c}\n")

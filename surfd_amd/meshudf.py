@@ -3,8 +3,8 @@
   GridFiller(N).fill_grid(udf_func, max_batch)   <- meshudf.py:23-206
   sample_udf / sample_grads                       <- meshudf.py:209-251
   get_udf_and_grads                               <- meshudf.py:254-304 (dense variant)
-  get_mesh_from_udf                               <- meshudf.py:307-348 (grid + gradients; the
-        marching-cubes / trimesh tail :349-437 is SURVEY.md §8 f1/f2 "next": pass ``mc_fn``)
+  get_mesh_from_udf                               <- meshudf.py:307-514 (grids on the GPU, native marching cubes on
+        the host, probe filter on the GPU, mesh cleaning / border smoothing in surfd_amd.meshproc)
 
 Two execution modes, same algorithm and same device-side index kernels:
   * native  — ``udf_func`` was made by ``surfd_amd.cbndec.make_udf_func``: one C call fills
@@ -20,6 +20,7 @@ import ctypes as C
 import math
 from typing import Callable, Dict, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import Tensor
@@ -170,18 +171,95 @@ def get_udf_and_grads(udf_func, coords_range: Tuple[float, float], max_dist: flo
 
 def get_mesh_from_udf(udf_func: Callable[[Tensor], Tensor], coords_range: Tuple[float, float], max_dist: float,
                       N: int = 128, smooth_borders: bool = True, differentiable: bool = True,
-                      max_batch: int = 2 ** 12, use_fast_grid_filler: bool = True, mc_fn=None):
-    """Grid + gradient stage of the reference function.  Returns (udf[N,N,N], grads[N,N,N,3])
-    device tensors when ``mc_fn`` is None; otherwise hands the host arrays to
-    ``mc_fn(udf_np, grads_np, spacing)`` (the udf_mc_lewiner contract)."""
-    if differentiable:
-        raise NotImplementedError("differentiable=True is never used by the sample scripts (SURVEY.md §3.4)")
+                      max_batch: int = 2 ** 12, use_fast_grid_filler: bool = True) -> Tuple[Tensor, Tensor]:
+    """Triangulated mesh of the zero set of a UDF — same signature, defaults and return value as the reference
+    (meshudf/meshudf.py:307-514): (vertices [V,3] float32, faces [F,3] int64) on the device.
+
+    Stages: coarse-to-fine grid + gradients on the GPU (one C call with the native decoder) -> native UDF marching
+    cubes on the host (csrc/mcubes.cpp, bit-identical to the reference's Cython extension) -> faces with any edge
+    end/mid point farther than 1/N from the surface are dropped (3 x 3F extra decoder queries, on the GPU) -> mesh
+    cleaning and border smoothing (surfd_amd.meshproc: numpy restatements of the trimesh calls) -> optionally the
+    reference's re-attachment of gradients to the vertex positions (``differentiable=True``; the sample scripts pass
+    False)."""
+    from . import meshproc as mp
+    from .mcubes import udf_mc_lewiner
     if not use_fast_grid_filler:
         udf, gradients = get_udf_and_grads(udf_func, coords_range, max_dist, N, max_batch)
     else:
         udf, gradients = GridFiller(N).fill_grid(udf_func, max_batch)
     udf[udf < 0] = 0
-    if mc_fn is None:
-        return udf, gradients
+    N = udf.shape[0]
+    dev = udf.device
     spacing = (coords_range[1] - coords_range[0]) / (N - 1)
-    return mc_fn(udf.cpu().numpy(), gradients.cpu().numpy(), [spacing] * 3)
+    vertices, faces, _, _ = udf_mc_lewiner(udf.detach().cpu().numpy(), gradients.detach().cpu().numpy(), spacing=[spacing] * 3)
+    del udf, gradients
+    vertices = vertices + coords_range[0]
+    faces = faces.astype(np.int64)
+
+    # faces whose corners or edge midpoints sit at large udf values are artefacts: drop them (meshudf.py:354-378)
+    edges, edge_face = mp.edges_of_faces(faces)
+    pa, pb = vertices[edges[:, 0]], vertices[edges[:, 1]]
+    probes = torch.from_numpy(np.vstack((pa, pb, (pa + pb) / 2))).float().to(dev)
+    far = sample_udf(udf_func, probes, max_batch).cpu().numpy() > 1 / N
+    keep = np.ones(len(faces), dtype=bool)
+    keep[np.unique(np.tile(edge_face, 3)[far])] = False
+    vertices, faces = mp.clean_until_stable(vertices, faces[keep])
+    if smooth_borders:
+        vertices = mp.smooth_borders(vertices, faces, lam=0.3, iterations=20)
+    final_verts = torch.tensor(vertices).float().to(dev)
+    final_faces = torch.tensor(faces).long().to(dev)
+    if not differentiable:
+        return final_verts, final_faces
+    return _reattach_gradients(udf_func, vertices, faces, final_verts, final_faces, 1 / N, max_batch, mp)
+
+
+def get_watertight_mesh(udf_func: Callable[[Tensor], Tensor], N: int, max_batch: int = 2 ** 16, level: float = 0.01,
+                        normalize: bool = False, classic: bool = True):
+    """The --watertight path of the reference's text / image drivers (sample/generate_text.py:132-158 with the
+    CPU-resident GridFiller of utils/utils.py:151-339): coarse-to-fine UDF grid WITHOUT gradients, then the closed
+    `level` iso-surface of the UDF (a thin solid around the sheet).  Returns (vertices [V,3] float64, faces [F,3]) on
+    the host.  Vertices are in voxel-index units like the file the reference ends up writing (it normalises a
+    component it then does not export); ``normalize=True`` maps them to [-1, 1]^3.  PyMCubes is not available here:
+    the surface comes from the native level-set mesher (classic triangle table by default) — same level set,
+    triangulation parity with PyMCubes unpinned.  Small-component removal is the caller's next step (5000 faces)."""
+    from .mcubes import marching_cubes
+    udf, _ = GridFiller(N).fill_grid(udf_func, max_batch, with_grads=False)
+    udf[udf < 0] = 0
+    verts, faces = marching_cubes(udf.detach().cpu().numpy(), level, classic=classic)
+    if normalize:
+        verts = verts * (2.0 / N) - 1.0
+    return verts, faces
+
+
+def _reattach_gradients(udf_func, vertices, faces, verts, final_faces, th_dist, max_batch, mp):
+    """meshudf.py:439-512: the vertex positions are re-expressed through udf samples taken at +-th_dist along the
+    normals (and, on borders, along the outward in-surface direction) so that d(vertices)/d(udf parameters) exists;
+    numerically the positions do not move (every added term is x - x.detach())."""
+    dev = verts.device
+    normals = torch.tensor(mp.vertex_normals_by_angle(vertices, faces)).float().to(dev)
+    s1 = sample_udf(udf_func, verts + th_dist * normals, max_batch, True).unsqueeze(-1)
+    s2 = sample_udf(udf_func, verts - th_dist * normals, max_batch, True).unsqueeze(-1)
+    z = th_dist * s1 * normals - th_dist * s2 * normals
+    new_verts = verts - z + z.detach()
+    rows = mp.border_edge_rows(faces)
+    if len(rows):
+        e = np.sort(mp.edges_of_faces(faces)[0][rows], axis=1)
+        partner = {}
+        for u, v in e:                                   # every border vertex keeps ONE of its border edges (the last seen)
+            partner[int(u)] = int(v)
+            partner[int(v)] = int(u)
+        u_b = np.fromiter(partner.keys(), dtype=np.int64)
+        v_b = np.fromiter(partner.values(), dtype=np.int64)
+        edge = torch.tensor(vertices[v_b] - vertices[u_b]).float().to(dev)
+        out_vec = torch.cross(edge, normals[u_b], dim=1)
+        out_vec = out_vec / (torch.norm(out_vec, dim=1, keepdim=True) + 1e-6)
+        bverts = torch.tensor(vertices[u_b]).float().to(dev)
+        b1 = sample_udf(udf_func, bverts + 3 * th_dist * out_vec, max_batch, True).unsqueeze(-1)
+        b2 = sample_udf(udf_func, bverts - 3 * th_dist * out_vec, max_batch, True).unsqueeze(-1)
+        out_vec = (-torch.argmax(torch.stack((b1, b2)), dim=0) * 2 + 1) * out_vec          # towards the larger udf
+        real = (b1 + b2)[:, 0] > th_dist                   # a true border leaves the surface on at least one side
+        big = torch.max(b1, b2)[real.unsqueeze(-1)]
+        shift = (th_dist * (big - big.detach())).unsqueeze(-1)
+        idx = torch.from_numpy(u_b).to(dev)[real]
+        new_verts[idx] = new_verts[idx] - shift * out_vec[real]
+    return new_verts, final_faces

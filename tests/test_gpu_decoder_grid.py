@@ -309,27 +309,65 @@ def test_sharded_field_single_rank_callback_path():
     assert torch.equal(udf_n, udf_s) and torch.equal(grads_n, grads_s)
 
 
-def test_reference_script_flow_end_to_end(tmp_path):
-    """examples/generate_uncond.py = the reference's generate_uncond.main() with only the imports changed:
-    synthetic checkpoints on disk in the reference layouts -> load -> DDIM-50 -> per-shape grids."""
+def _run_driver(argv):
     import importlib.util
     import os
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("gen_uncond_example", os.path.join(root, "examples", "generate_uncond.py"))
+    spec = importlib.util.spec_from_file_location("generate_driver", os.path.join(root, "examples", "generate.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    argv = sys.argv
-    sys.argv = ["x", "--synthetic", "--num_samples", "2", "--resolution", "64", "--respacing", "ddim50",
-                "--output_dir", str(tmp_path)]
-    try:
-        sample, results = mod.main()
-    finally:
-        sys.argv = argv
-    assert sample.shape == (2, 1, 32) and torch.isfinite(sample).all()
-    for udf, grads in results:
-        assert udf.shape == (64, 64, 64) and grads.shape == (64, 64, 64, 3)
-        assert float(udf.min()) >= 0.0 and float(udf.max()) <= 0.1 + 1e-6
+    return mod.main(argv)
+
+
+def _read_obj(path):
+    v, f = [], []
+    for line in open(path):
+        if line.startswith("v "):
+            v.append([float(t) for t in line.split()[1:4]])
+        elif line.startswith("f "):
+            f.append([int(t) - 1 for t in line.split()[1:4]])
+    return np.array(v), np.array(f)
+
+
+@pytest.mark.parametrize("mode,extra", [("uncond", []), ("cat", ["--category", "3"]), ("text", ["--guidance_param", "3.0"]),
+                                        ("image", ["--watertight"])])
+def test_driver_caller_contract_end_to_end(tmp_path, mode, extra):
+    """The caller contract of the sample scripts, end to end on the GPU: checkpoints in the reference
+    layouts on disk -> create_model_and_diffusion / load_model_wo_clip / (CFG wrapper) -> p_sample_loop ->
+    CbnDecoder.load_state_dict(strict) -> get_mesh_from_udf (or the watertight path) -> OBJ files."""
+    latents, written = _run_driver([mode, "--synthetic", "--num_samples", "2", "--resolution", "64", "--respacing", "ddim20",
+                                    "--output_dir", str(tmp_path)] + extra)
+    L = 64 if mode in ("text", "image") else 32
+    assert latents.shape == (2, 1, L) and torch.isfinite(latents).all()
+    assert len(written) == 2
+    for path, nv, nf in written:
+        v, f = _read_obj(path)
+        assert v.shape == (nv, 3) and f.shape == (nf, 3)
+        if nf:
+            assert f.min() >= 0 and f.max() < nv and np.isfinite(v).all()
+
+
+def test_get_mesh_from_udf_on_a_known_surface():
+    """get_mesh_from_udf with an arbitrary callable (the reference contract) on the analytic thin shell: the mesh lies
+    on the surface, is returned as (float32 vertices, int64 faces) on the device, and is an OPEN surface whose border
+    (the rim) survives cleaning; differentiable=True returns the same positions with a graph attached."""
+    from surfd_amd.meshudf import get_mesh_from_udf
+
+    def field(c):
+        return ogrid.analytic_field(c.cpu()).to(c.device) if not c.requires_grad else _analytic_torch(c)
+
+    def _analytic_torch(c):
+        x, y, z = c[:, 0], c[:, 1], c[:, 2]
+        up = (torch.sqrt(x * x + y * y + z * z) - 0.6).abs()
+        rho = torch.sqrt(x * x + y * y) - 0.6
+        return torch.clamp(torch.where(z >= 0, up, torch.sqrt(rho * rho + z * z)), max=0.1)
+    v, t = get_mesh_from_udf(_analytic_torch, coords_range=(-1, 1), max_dist=0.1, N=128, max_batch=2 ** 16, differentiable=False)
+    assert v.dtype == torch.float32 and t.dtype == torch.int64 and v.is_cuda and t.is_cuda
+    assert len(v) > 10000 and int(t.max()) == len(v) - 1
+    assert float(_analytic_torch(v).max()) < 1.0 / 128 + 1e-3        # every vertex (after smoothing) within ~a voxel of the surface
+    v2, t2 = get_mesh_from_udf(_analytic_torch, coords_range=(-1, 1), max_dist=0.1, N=128, max_batch=2 ** 16, differentiable=True)
+    assert torch.equal(t, t2)
+    np.testing.assert_allclose(v2.detach().cpu().numpy(), v.cpu().numpy(), atol=1e-6)
 
 
 def test_decoder_f16x2_vs_fp32_kernel(golden):
@@ -434,3 +472,34 @@ def test_callback_point_lists_are_in_voxel_order():
     for lvl_pts in seen[1:-1]:                          # levels >= 1: 7 children per parent, parents ascending
         corners = flat(lvl_pts.reshape(-1, 7, 3)[:, 0, :])
         assert bool((corners[1:] > corners[:-1]).all())
+
+
+def test_mesh_512_thin_shell_end_to_end(golden):
+    """SURVEY.md §8c G11 at full size: GridFiller(512) on the GPU (analytic thin-shell field through the callback
+    path, bit-exact grid) -> native marching cubes on the host must give the reference's 222 793 vertices /
+    444 357 faces, with the very same arrays (SHA-256 of the reference's output)."""
+    import hashlib
+    from surfd_amd import mcubes
+    from surfd_amd.meshudf import GridFiller
+    g = golden("g13_marching_cubes")
+
+    class Field:
+        def __call__(self, c):
+            return ogrid.analytic_field(c.cpu()).cuda()
+
+        def grads(self, c, max_batch):
+            # the oracle's analytic gradient: -normalize(d u / d p) by autograd on the CPU restatement
+            p = c.detach().cpu().clone().requires_grad_(True)
+            ogrid.analytic_field(p).sum().backward()
+            return (-torch.nn.functional.normalize(p.grad, dim=1)).cuda()
+    udf, grads = GridFiller(512).fill_grid(Field(), 2 ** 30)
+    udf[udf < 0] = 0
+    import time
+    t0 = time.time()
+    v, f, _, _ = mcubes.udf_mc_lewiner(udf.cpu().numpy(), grads.cpu().numpy())
+    print(f"native marching cubes at 512^3: {len(v)} vertices / {len(f)} faces in {time.time() - t0:.2f} s (one host core)")
+    assert (len(v), len(f)) == (222793, 444357) == (int(g["thin_shell_512_nv"]), int(g["thin_shell_512_nf"]))
+    assert hashlib.sha256(np.ascontiguousarray(f, np.int32).tobytes()).hexdigest() == str(g["thin_shell_512_faces_sha256"])
+    assert hashlib.sha256(np.ascontiguousarray(v, np.float32).tobytes()).hexdigest() == str(g["thin_shell_512_verts_sha256"])
+    del udf, grads
+    torch.cuda.empty_cache()

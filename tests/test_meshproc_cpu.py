@@ -1,0 +1,133 @@
+"""surfd_amd.meshproc — numpy restatements of the trimesh calls behind get_mesh_from_udf.
+
+No trimesh exists in this environment: these are pinned by hand-checkable fixtures ("parity unpinned vs trimesh");
+each test states the trimesh behaviour it encodes."""
+import numpy as np
+import pytest
+
+from surfd_amd import meshproc as mp
+
+TET_V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float64)
+TET_F = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])         # outward winding
+
+
+def _edge_use(faces):
+    e, _ = mp.edges_of_faces(faces)
+    _, c = np.unique(np.sort(e, axis=1), axis=0, return_counts=True)
+    return c
+
+
+def test_edges_are_face_major_directed_triples():
+    e, ef = mp.edges_of_faces(np.array([[5, 6, 7], [7, 6, 8]]))
+    np.testing.assert_array_equal(e, [[5, 6], [6, 7], [7, 5], [7, 6], [6, 8], [8, 7]])
+    np.testing.assert_array_equal(ef, [0, 0, 0, 1, 1, 1])
+
+
+def test_cull_and_merge_keeps_first_occurrence_order():
+    """process(): unreferenced vertices vanish, coincident ones (to 1e-8) merge, survivors stay in first-seen order."""
+    v = np.array([[9, 9, 9],            # 0 unreferenced
+                  [1, 0, 0],            # 1
+                  [0, 0, 0],            # 2
+                  [0, 1, 0],            # 3
+                  [1, 0, 0 + 4e-9],     # 4 == 1 within 1e-8
+                  [0, 0, 1]], float)    # 5
+    f = np.array([[2, 1, 3], [2, 4, 5]])
+    nv, nf = mp.cull_and_merge(v, f)
+    np.testing.assert_allclose(nv, [[1, 0, 0], [0, 0, 0], [0, 1, 0], [0, 0, 1]], atol=1e-8)
+    np.testing.assert_array_equal(nf, [[1, 0, 2], [1, 0, 3]])
+    # idempotent
+    v2, f2 = mp.cull_and_merge(nv, nf)
+    np.testing.assert_array_equal(v2, nv); np.testing.assert_array_equal(f2, nf)
+    # non-finite vertices take their faces with them
+    v[3, 0] = np.nan
+    nv, nf = mp.cull_and_merge(v, f)
+    assert len(nf) == 1 and np.isfinite(nv).all() and len(nv) == 3
+
+
+def test_duplicate_faces_ignore_winding_and_follow_sorted_key_order():
+    f = np.array([[3, 4, 5], [0, 1, 2], [2, 1, 0], [1, 2, 0], [5, 3, 4], [0, 1, 3]])
+    out = mp.drop_duplicate_faces(f)
+    # survivors = first occurrences, ordered by (max, mid, min) vertex: {0,1,2} < {0,1,3} < {3,4,5}
+    np.testing.assert_array_equal(out, [[0, 1, 2], [0, 1, 3], [3, 4, 5]])
+    assert mp.drop_duplicate_faces(np.zeros((0, 3), int)).shape == (0, 3)
+
+
+def test_degenerate_faces_by_height():
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [2, 0, 0], [0.5, 1e-9, 0], [0, 0, 0]], float)
+    f = np.array([[0, 1, 2],      # fine
+                  [0, 1, 3],      # collinear: zero area
+                  [0, 1, 4],      # height 1e-9 < 1e-8
+                  [0, 5, 2]])     # two coincident corners: an edge of zero length
+    np.testing.assert_array_equal(mp.drop_degenerate_faces(v, f), [[0, 1, 2]])
+
+
+def test_border_rows_and_watertightness():
+    assert len(mp.border_edge_rows(TET_F)) == 0                      # closed: every edge twice
+    open_f = TET_F[:3]
+    rows = mp.border_edge_rows(open_f)
+    e, _ = mp.edges_of_faces(open_f)
+    assert sorted(map(tuple, np.sort(e[rows], axis=1))) == [(0, 2), (0, 3), (2, 3)]
+
+
+def test_single_triangle_hole_is_closed_with_consistent_winding():
+    filled = mp.fill_small_holes(TET_V, TET_F[:3])
+    assert len(filled) == 4 and (_edge_use(filled) == 2).all()
+    # consistent orientation: every directed edge appears once in each direction
+    e, _ = mp.edges_of_faces(filled)
+    assert set(map(tuple, e)) == set(map(tuple, e[:, ::-1]))
+    # outward: the signed volume stays positive
+    t = TET_V[filled]
+    assert np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() > 0
+
+
+def test_quad_hole_gets_two_triangles_and_large_holes_stay_open():
+    # a cube as 12 triangles, remove both triangles of the top face -> a 4-edge hole
+    V = np.array([[x, y, z] for z in (0, 1) for y in (0, 1) for x in (0, 1)], float)
+    quads = [(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5)]
+    F = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))])
+    assert (_edge_use(F) == 2).all()
+    holed = np.array([f for f in F if not set(f) <= {4, 5, 6, 7}])
+    assert len(holed) == 10
+    filled = mp.fill_small_holes(V, holed)
+    assert len(filled) == 12 and (_edge_use(filled) == 2).all()
+    e, _ = mp.edges_of_faces(filled)
+    assert set(map(tuple, e)) == set(map(tuple, e[:, ::-1]))
+    # a 6-edge hole (two adjacent cube faces removed) is left alone
+    holed6 = np.array([f for f in F if not (set(f) <= {4, 5, 6, 7} or set(f) <= {1, 3, 5, 7})])
+    assert len(mp.fill_small_holes(V, holed6)) == len(holed6)
+
+
+def test_border_smoothing_moves_only_the_border_and_converges_to_neighbour_means():
+    # a 5x5 flat grid of quads (two triangles each); lift one border vertex and one interior vertex
+    n = 5
+    V = np.array([[i, j, 0.0] for i in range(n) for j in range(n)])
+    idx = lambda i, j: i * n + j
+    F = np.array([t for i in range(n - 1) for j in range(n - 1)
+                  for t in ((idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)), (idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)))])
+    V[idx(0, 2), 2] = 1.0
+    V[idx(2, 2), 2] = 1.0
+    one = mp.smooth_borders(V, F, lam=0.3, iterations=1)
+    assert one[idx(2, 2), 2] == 1.0                                   # interior untouched
+    assert one[idx(0, 2), 2] == pytest.approx(0.7)                    # 1 + 0.3 * (0 - 1): both border neighbours at 0
+    assert one[idx(0, 1), 2] == pytest.approx(0.15)                   # 0 + 0.3 * ((1 + 0) / 2 - 0), from the OLD state
+    many = mp.smooth_borders(V, F)
+    assert abs(many[idx(0, 2), 2]) < 0.2 and many[idx(2, 2), 2] == 1.0
+    np.testing.assert_array_equal(many[:, :2][[idx(1, 1), idx(2, 2)]], V[:, :2][[idx(1, 1), idx(2, 2)]])
+    # closed mesh: nothing moves
+    np.testing.assert_array_equal(mp.smooth_borders(TET_V, TET_F), TET_V)
+
+
+def test_angle_weighted_normals():
+    n = mp.vertex_normals_by_angle(TET_V, TET_F)
+    np.testing.assert_allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-12)
+    np.testing.assert_allclose(n[0], -np.ones(3) / np.sqrt(3), atol=1e-12)     # three right angles, three axis faces
+    flat = mp.vertex_normals_by_angle(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], float), np.array([[0, 1, 2], [1, 3, 2]]))
+    np.testing.assert_allclose(flat, np.tile([0, 0, 1.0], (4, 1)), atol=1e-12)
+
+
+def test_clean_until_stable_pipeline():
+    # tetrahedron with a duplicated vertex, a duplicated face, a degenerate face and one face missing
+    V = np.vstack([TET_V, TET_V[1] + 1e-10, [[5, 5, 5]]])
+    F = np.array([[0, 2, 1], [0, 4, 3], [1, 2, 3], [2, 1, 0], [1, 4, 2]])       # [0,3,2] missing; [1,4,2] collapses
+    v, f = mp.clean_until_stable(V, F)
+    assert len(v) == 4 and len(f) == 4 and (_edge_use(f) == 2).all()

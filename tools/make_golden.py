@@ -414,17 +414,59 @@ def g9_d64(R):
          grad_nonzero=int((grads.abs().sum(-1) > 0).sum()), udf_sum=float(udf.double().sum()))
 
 
+
+def g13_marching_cubes(R, with_512: bool):
+    """G11 of SURVEY.md §8c: the reference's own compiled UDF marching cubes (oracle/build_ref.py builds
+    meshudf/_marching_cubes_lewiner_cy.pyx into oracle/_ref/) on deterministic synthetic grids (tests/mc_fields.py):
+    counts + SHA-256 of the vertex / face arrays for every case, full arrays for the small ones."""
+    import base64
+    import importlib.util
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import mc_fields
+    from oracle import build_ref
+    cy = build_ref.load()
+    assert cy is not None, "oracle/_ref could not be built"
+    spec = importlib.util.spec_from_file_location("ref_luts", os.path.join("/root/reference", "meshudf", "_marching_cubes_lewiner_luts.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tables = {n: np.frombuffer(base64.decodebytes(getattr(mod, n)[1].encode()), dtype=np.int8).reshape(getattr(mod, n)[0])
+              for n in build_ref.LUT_ORDER[3:]}
+    tables["EDGESRELX"] = np.array([[0, 1], [1, 1], [1, 0], [0, 0], [0, 1], [1, 1], [1, 0], [0, 0], [0, 0], [1, 1], [1, 1], [0, 0]], np.int8)
+    tables["EDGESRELY"] = np.array([[0, 0], [0, 1], [1, 1], [1, 0], [0, 0], [0, 1], [1, 1], [1, 0], [0, 0], [0, 0], [1, 1], [1, 1]], np.int8)
+    tables["EDGESRELZ"] = np.array([[0, 0], [0, 0], [0, 0], [0, 0], [1, 1], [1, 1], [1, 1], [1, 1], [0, 1], [0, 1], [0, 1], [0, 1]], np.int8)
+    cases = [("two_spheres", 48), ("two_spheres", 96), ("open_sheet", 48), ("open_sheet", 96), ("noisy_blob", 48),
+             ("noisy_blob", 96), ("thin_shell", 64), ("thin_shell", 128), ("thin_shell", 256)]
+    if with_512:
+        cases.append(("thin_shell", 512))
+    out = {}
+    for name, N in cases:
+        udf, grads = mc_fields.FIELDS[name](N)
+        t0 = time.time()
+        v, f, n, val = build_ref.reference_udf_mc(cy, tables, udf, grads)
+        tag = f"{name}_{N}"
+        out[tag + "_nv"], out[tag + "_nf"] = np.array(len(v)), np.array(len(f))
+        out[tag + "_verts_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(v, np.float32).tobytes()).hexdigest())
+        out[tag + "_faces_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(f, np.int32).tobytes()).hexdigest())
+        if N <= 48:
+            out[tag + "_verts"], out[tag + "_faces"] = np.ascontiguousarray(v, np.float32), np.ascontiguousarray(f, np.int32)
+            out[tag + "_normals"] = np.ascontiguousarray(n, np.float32)
+        print(f"  reference marching_cubes_udf {tag}: {len(v)} verts / {len(f)} faces in {time.time() - t0:.2f}s")
+    save("g13_marching_cubes", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default="")
     ap.add_argument("--g10-sizes", default="64,128,256")
+    ap.add_argument("--mc512", action="store_true", help="g13: also mesh the 512^3 thin shell (minutes of CPU)")
     a = ap.parse_args()
     torch.manual_seed(0)
     R = import_reference(a.ref)
     jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
             "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
-            "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R)}
+            "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R),
+            "g13": lambda: g13_marching_cubes(R, a.mc512)}
     only = [s for s in a.only.split(",") if s]
     for name, fn in jobs.items():
         if only and name not in only:
