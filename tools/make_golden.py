@@ -445,6 +445,9 @@ def g13_marching_cubes(R, with_512: bool):
         v, f, n, val = build_ref.reference_udf_mc(cy, tables, udf, grads)
         tag = f"{name}_{N}"
         out[tag + "_nv"], out[tag + "_nf"] = np.array(len(v)), np.array(len(f))
+        # the INPUT grid's hash: sin / sqrt of the math libraries differ in the last bit between CPUs, so a test on
+        # another host first checks that it is meshing the very same grid before comparing output hashes
+        out[tag + "_input_sha256"] = np.array(hashlib.sha256(udf.tobytes() + grads.tobytes()).hexdigest())
         out[tag + "_verts_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(v, np.float32).tobytes()).hexdigest())
         out[tag + "_faces_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(f, np.int32).tobytes()).hexdigest())
         if N <= 48:
