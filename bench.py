@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--decoder-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="forward decoder kernel arithmetic (include/surfd_hip.h: surfd_decoder_set_precision)")
-    ap.add_argument("--decoder-blocks", type=int, default=208,
+    ap.add_argument("--decoder-blocks", type=int, default=192,
                     help="with --pipeline 1: persistent decoder workgroups per launch while the next batch's reverse loop "
                          "runs on the remaining CUs (the last batch's grids, with nothing left to overlap, use every CU)")
     ap.add_argument("--pipeline", type=int, default=1,

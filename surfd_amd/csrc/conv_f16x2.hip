@@ -31,6 +31,8 @@ namespace surfd {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16x8 __attribute__((address_space(1))) gf16x8;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Seg2 {
     const float *x;        // source view (channel offset applied)
@@ -140,7 +142,9 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     }
     const int nblk0 = A.seg[0].nblk;
     const int nch = nblk0 + (A.nseg > 1 ? A.seg[1].nblk : 0);
-    const int cs = A.cs, plane = A.plane;
+    // the low fp16 plane of the slab sits PLANE halfs behind the high one: a compile-time LDS offset
+    constexpr int PLANE = VEC == 16 ? 18432 : 14336;
+    const int cs = A.cs;
     const float inv_sc = A.sc[1];
 
     // two accumulators: the two small cross terms (xl*wh, xh*wl) share one, the main term has its own; a third
@@ -248,37 +252,65 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
             const int ups = A.seg[s].ups, act = A.seg[s].act;
             if (A.seg[s].gn) {
                 const int gs = A.seg[s].gs;
-                // per-float4 (mean, M2); equal-size pieces combine exactly (Chan et al.)
+                // ---- GroupNorm statistics, two-pass, in registers first: per (batch row, channel) mean and M2 over the
+                //      row's Lin positions.  A row is 2^lv consecutive float4 of this thread; the sums go up a binary
+                //      tree whose levels are enabled by the (wave-uniform) lv, every member of a block ending up with the
+                //      block's total — no register is ever indexed dynamically.
+                constexpr int LOG2VEC = VEC == 16 ? 4 : 3;
+                float rs[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) rs[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+                auto tree = [&](float (&t)[VEC]) {
+#pragma unroll
+                    for (int lev = 0; lev < LOG2VEC; ++lev)
+                        if (lev < lv) {
+#pragma unroll
+                            for (int j = 0; j < VEC; j += 2 << lev) {
+                                const float tot = t[j] + t[j + (1 << lev)];
+#pragma unroll
+                                for (int m = 0; m < (2 << lev); ++m) t[j + m] = tot;
+                            }
+                        }
+                };
+                tree(rs);
+                const float inv_len = 1.f / (float)Lin;
+                float rm2[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float mv = ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) * 0.25f;
+                    rs[j] *= inv_len;                                  // row mean, seen from every float4 of the row
                     float m2 = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float d = v[j][q] - mv; m2 += d * d; }
-                    ex_mean[j * 256 + c] = mv;
-                    ex_m2[j * 256 + c] = m2;
+                    for (int q = 0; q < 4; ++q) { const float d = v[j][q] - rs[j]; m2 += d * d; }
+                    rm2[j] = m2;
                 }
+                tree(rm2);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if ((j & (vpr - 1)) == 0 && (j >> lv) < nb) {     // first float4 of a live row (uniform)
+                        ex_mean[(j >> lv) * 256 + c] = rs[j];
+                        ex_m2[(j >> lv) * 256 + c] = rm2[j];
+                    }
                 lds_bar();
                 C2_STAMP_FIRST(2);
+                // ---- per (batch row, group): equal-size rows combine exactly (Chan et al.):
+                //      mean = avg(row means),  M2 = sum(row M2) + Lin * sum((row mean - mean)^2); 8 lanes per group
                 const int ng = blk / gs, nq = nb * ng;
-                const float inv_n = 1.f / (float)(gs * vpr), inv_cnt = 1.f / (float)(gs * Lin);
+                const float inv_gs = 1.f / (float)gs, inv_cnt = 1.f / (float)(gs * Lin), flin = (float)Lin;
                 for (int q0 = 0; q0 < nq; q0 += 32) {
                     const int q = q0 + (tid >> 3), lt = tid & 7;
                     const bool qok = q < nq;
                     const int i = qok ? q / ng : 0;
                     const int g = qok ? q - i * ng : 0;
-                    const float *pm = ex_mean + (i * vpr) * 256 + g * gs;
-                    const float *p2 = ex_m2 + (i * vpr) * 256 + g * gs;
+                    const float *pm = ex_mean + i * 256 + g * gs;
+                    const float *p2 = ex_m2 + i * 256 + g * gs;
                     float sm = 0.f;
                     if (qok)
-                        for (int jj = 0; jj < vpr; ++jj)
-                            for (int k = lt; k < gs; k += 8) sm += pm[jj * 256 + k];
+                        for (int k = lt; k < gs; k += 8) sm += pm[k];
                     sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 1);
-                    const float gm = sm * inv_n;
+                    const float gm = sm * inv_gs;
                     float m2 = 0.f;
                     if (qok)
-                        for (int jj = 0; jj < vpr; ++jj)
-                            for (int k = lt; k < gs; k += 8) { const float d = pm[jj * 256 + k] - gm; m2 += p2[jj * 256 + k] + 4.f * (d * d); }
+                        for (int k = lt; k < gs; k += 8) { const float d = pm[k] - gm; m2 += p2[k] + flin * (d * d); }
                     m2 += __shfl_xor(m2, 4); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 1);
                     if (qok && lt == 0) { gstat[2 * q] = gm; gstat[2 * q + 1] = 1.f / sqrtf(m2 * inv_cnt + 1e-5f); }
                 }
@@ -305,33 +337,43 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[j][k] = silu2(v[j][k]);
             }
-            // ---- split and write the slab [batch row][position][channel]; zero halo positions and padded channels ----
-            if (c < blkp) {
-                const int Lcov = ups ? 2 * Lin : Lin;
+            // ---- split and write the slab [batch row][position][channel]; zero halo positions and padded channels.
+            //      Two positions at a time: one packed conversion per pair, the halves stored with ds_write_b16 /
+            //      ds_write_b16_d16_hi; the low plane sits at a compile-time offset (an LDS immediate, no address math).
+            const int rstep = ups ? 2 : 1;
+            const int Lcov = ups ? 2 * Lin : Lin;
+            if (cok) {
+                float amax = 0.f;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int i = j >> lv, jj = j & (vpr - 1);
                     if (i < nb) {
+                        _Float16 *row = slab + (i * A.Lsl + pad + rstep * 4 * jj) * cs + c;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float w0 = cok ? v[j][k] : 0.f;
-                            saturated |= fabsf(w0) > 65504.f;
-                            const float w = __builtin_amdgcn_fmed3f(w0, -65504.f, 65504.f);
-                            const _Float16 h = (_Float16)w;
-                            const _Float16 lo = (_Float16)(w - (float)h);
-                            const int l = 4 * jj + k;
-                            _Float16 *dst = slab + (i * A.Lsl + pad + (ups ? 2 * l : l)) * cs + c;
-                            dst[0] = h; dst[plane] = lo;
-                            if (ups) { dst[cs] = h; dst[cs + plane] = lo; }
+                        for (int k = 0; k < 4; k += 2) {
+                            amax = fmaxf(amax, fmaxf(fabsf(v[j][k]), fabsf(v[j][k + 1])));
+                            const f32x2 w = {__builtin_amdgcn_fmed3f(v[j][k], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[j][k + 1], -65504.f, 65504.f)};
+                            const f16x2 h = __builtin_convertvector(w, f16x2);
+                            const f32x2 hf = __builtin_convertvector(h, f32x2);
+                            const f16x2 lo = __builtin_convertvector(w - hf, f16x2);
+                            _Float16 *d0 = row + (k * rstep) * cs, *d1 = d0 + rstep * cs;
+                            d0[0] = h[0]; d0[PLANE] = lo[0];
+                            d1[0] = h[1]; d1[PLANE] = lo[1];
+                            if (ups) { d0[cs] = h[0]; d0[cs + PLANE] = lo[0]; d1[cs] = h[1]; d1[cs + PLANE] = lo[1]; }
                         }
                     }
                 }
+                saturated |= amax > 65504.f;
+            } else if (c < blkp) {                 // channels that only exist as padding of the K block: zeros
+                for (int i = 0; i < nb; ++i)
+                    for (int p = pad; p < pad + Lcov; ++p) { slab[(i * A.Lsl + p) * cs + c] = (_Float16)0.f; slab[(i * A.Lsl + p) * cs + c + PLANE] = (_Float16)0.f; }
+            }
+            if (c < blkp)
                 for (int i = 0; i < nb; ++i) {
                     _Float16 *row0 = slab + (i * A.Lsl) * cs + c;
-                    for (int p = 0; p < pad; ++p) { row0[p * cs] = (_Float16)0.f; row0[p * cs + plane] = (_Float16)0.f; }
-                    for (int p = pad + Lcov; p < A.Lsl; ++p) { row0[p * cs] = (_Float16)0.f; row0[p * cs + plane] = (_Float16)0.f; }
+                    for (int p = 0; p < pad; ++p) { row0[p * cs] = (_Float16)0.f; row0[p * cs + PLANE] = (_Float16)0.f; }
+                    for (int p = pad + Lcov; p < A.Lsl; ++p) { row0[p * cs] = (_Float16)0.f; row0[p * cs + PLANE] = (_Float16)0.f; }
                 }
-            }
             lds_bar();
             C2_STAMP_FIRST(4);
         }
@@ -354,7 +396,7 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
                         const int tap = (it >= nk) + (it >= 2 * nk);
                         const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
                         const f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
-                        const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + plane);
+                        const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + PLANE);
                         acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_sm, 0, 0, 0);
                         acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
                         acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm, 0, 0, 0);
@@ -669,14 +711,16 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.Lsl = max_lsl;
     const int VEC = Lin0 == 64 ? 16 : 8;
     int nb = std::min({B, (VEC * 4) / Lin0, std::max(1, 64 / A.Lout), 8});
-    // keep the slab under ~56 KB so that two workgroups (of this or of a concurrent sampling loop) share a CU
-    while (nb > 1 && (size_t)nb * A.Lsl * (max_blkp + 8) * 4 > 56 * 1024) --nb;
+    // one fp16 plane of the slab has a fixed size (the kernel addresses the low plane with an immediate): 28 KB
+    // (36 KB for 64-long rows), i.e. <= 74 KB of LDS per workgroup so that two of them share a CU
+    const size_t plane_halfs = VEC == 16 ? 18432 : 14336;
+    while (nb > 1 && (size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) --nb;
+    if ((size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) return 1;
     if (nb * A.Lout > 64) return 1;
     A.bchunk = nb;
     A.cs = max_blkp + 8;
-    const int rows = nb * A.Lsl;
-    A.plane = rows * A.cs;
-    size_t lds = (size_t)A.plane * 2 * sizeof(_Float16);
+    A.plane = (int)plane_halfs;
+    size_t lds = plane_halfs * 2 * sizeof(_Float16);
     lds = (lds + 15) & ~(size_t)15;
     // GroupNorm exchange area (staging) and k-part reduction scratch (after the last MFMA) are never live together
     A.off_ex = (int)lds;

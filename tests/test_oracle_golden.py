@@ -201,6 +201,7 @@ def test_g11_conditioned_ddim50(golden, unet_sd):
     B, L = 8, 64
     for name in ("g11_ddim50_img_B8_L64", "g11_ddim50_textcfg_B8_L64"):
         g = golden(name)
+        unet_sd = synth.synth_unet_state_dict(head_gain=float(g["head_gain"]))
         noise = synth.synth_noise_batch(50, 0, B, L, seed=int(g["seed"]))
         ctx = synth.synth_context(0, B, seed=int(g["ctx_seed"]))
         if "scale" in g.files:
@@ -214,7 +215,7 @@ def test_g11_conditioned_ddim50(golden, unet_sd):
             model = lambda xx, tt: ounet.unet_forward(unet_sd, xx, tt, context=ctx)
         x, rec = odiff.sample_loop(odiff.make_schedule(respacing="ddim50"), model, noise, sampler="ddim", record=[0, 24, 49])
         for k in (0, 24, 49):
-            np.testing.assert_allclose(rec[k].numpy(), g[f"x_after_{k}"], rtol=1e-3, atol=2e-4)
+            np.testing.assert_allclose(rec[k].numpy(), g[f"x_after_{k}"], rtol=0, atol=1e-5)
 
 
 def test_g12_ddpm1000_contractive_end_to_end(golden):

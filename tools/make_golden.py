@@ -356,22 +356,23 @@ def g11_conditioned_loops(R):
     classifier-free wrapper with scale 3.0 (the CLIP tower replaced by a fixed embedding table)."""
     B, L = 8, 64
     ctx = synth.synth_context(0, B)
+    gain = synth.CONTRACTIVE_HEAD_GAIN      # contractive head: the 50-step trajectory is comparable to ~1e-6, not 1e-3
     # C5: image-conditioned, 50-step DDIM (eta 0)
-    model, _ = build_model(R, "img")
+    model, _ = build_model(R, "img", head_gain=gain)
     noise = synth.synth_noise_batch(50, 0, B, L)
     t0 = time.time()
     rec = run_loop(R, model, ddim50(R), (B, 1, L), noise, "ddim", {"y": {"context": ctx}}, (0, 24, 49))
     print(f"  reference img-cond DDIM-50 B={B} L={L}: {time.time() - t0:.1f}s")
-    save("g11_ddim50_img_B8_L64", seed=1234, ctx_seed=77, **rec)
+    save("g11_ddim50_img_B8_L64", seed=1234, ctx_seed=77, head_gain=gain, **rec)
     # C4: text-conditioned + CFG wrapper, 50-step DDIM
     install_fake_clip(ctx)
-    model, _ = build_model(R, "text")
+    model, _ = build_model(R, "text", head_gain=gain)
     wrapped = R.cfg_sampler.ClassifierFreeSampleModel(model)
     kw = {"y": {"text": [str(i) for i in range(B)], "scale": torch.ones(B) * 3.0}}
     t0 = time.time()
     rec = run_loop(R, wrapped, ddim50(R), (B, 1, L), noise, "ddim", kw, (0, 24, 49))
     print(f"  reference text+CFG DDIM-50 B={B} L={L}: {time.time() - t0:.1f}s")
-    save("g11_ddim50_textcfg_B8_L64", seed=1234, ctx_seed=77, scale=3.0, **rec)
+    save("g11_ddim50_textcfg_B8_L64", seed=1234, ctx_seed=77, scale=3.0, head_gain=gain, **rec)
 
 
 def g12_contractive(R):
