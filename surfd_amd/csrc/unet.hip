@@ -9,8 +9,8 @@
 //                  (Upsample :91-119), channel concat of the skip connection as a second
 //                  K-segment (1x1 skip_connection conv, :240-241), and in the epilogue bias,
 //                  the per-(t,sample) ResBlock embedding add (:264-271) and the residual add.
-//   attn_kernel  — QKVAttentionLegacy (:356-372) for one (sample, head): sequence length <= 64,
-//                  head dims 28/56/112, softmax in fp32; 0.4 % of the FLOPs, plain VALU.
+//   attn_kernel  — QKVAttentionLegacy (:356-372): QK^T, softmax and PV of one (sample, head, 32-query tile) per wave on
+//                  fp32 MFMA with LDS-staged q/k/v; the probabilities never leave the accumulator registers.
 //   temb_kernel  — timestep_embedding (utils/ldm_utils.py:165-185).
 //
 // Everything that depends only on (timestep, conditioning) — time_embed MLP, label/context
@@ -546,49 +546,128 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// attention core: one workgroup per (sample, head)
+// attention core on the matrix pipe: one workgroup per (sample, head, 32-query tile)
 // ---------------------------------------------------------------------------------------------
+// QKVAttentionLegacy (openaimodel.py:356-372): w = softmax_s((q * d^-1/4)^T (k * d^-1/4)), a = v w^T, per head, T <= 64,
+// d = C / 8 in {28, 56, 112}.  q, k, v of the head are staged in LDS as [channel][T]; all three contractions run on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation):
+//   S^T[s][t] = sum_c k[c][s] q[c][t]     keys along the accumulator ROWS, queries along the columns: a query's 32 (or 64)
+//                                          scores then live in the 16 (32) accumulator registers of two lanes, so the
+//                                          softmax over keys is register-local plus ONE cross-lane exchange;
+//   a[c][t]   = sum_s v[c][s] P[s][t]      the probabilities are consumed as the MFMA B operand straight from those
+//                                          registers: k-step r contracts keys frag_row(r, 0) and frag_row(r, 1), which is
+//                                          exactly what lane halves 0 / 1 hold in register r — P never touches LDS.
 __global__ __launch_bounds__(256) void attn_kernel(const float *qkv, long qkv_bstride, float *out, long out_bstride,
                                                    int heads, int d, int T, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int tid = threadIdx.x;
-    float *q = lds, *k = q + d * T, *v = k + d * T, *w = v + d * T;   // q,k,v: [d][T]; w: [T][T+1]
-    const float *src = qkv + b * qkv_bstride + (long)h * 3 * d * T;    // head-major [q | k | v] runs
-    for (int e = tid; e < 3 * d * T; e += 256) {
-        float x = src[e];
-        if (e < 2 * d * T) x *= scale;        // (q*scale), (k*scale) as the reference forms them
-        lds[e] = x;
-    }
-    __syncthreads();
-    for (int e = tid; e < T * T; e += 256) {
-        const int t = e / T, s = e % T;
-        float a = 0.f;
-        for (int c = 0; c < d; ++c) a += q[c * T + t] * k[c * T + s];
-        w[t * (T + 1) + s] = a;
-    }
-    __syncthreads();
-    // softmax over keys: 4 lanes per query row (T <= 64 rows -> all 256 threads busy), shuffle-combined
-    {
-        const int t = tid >> 2, lt = tid & 3;
-        if (t < T) {
-            float *row = w + t * (T + 1);
-            float mx = -INFINITY;
-            for (int s = lt; s < T; s += 4) mx = fmaxf(mx, row[s]);
-            mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
-            float sum = 0.f;
-            for (int s = lt; s < T; s += 4) { const float ex = expf(row[s] - mx); row[s] = ex; sum += ex; }
-            sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 1);
-            for (int s = lt; s < T; s += 4) row[s] /= sum;
+    const int qt_n = (T + 31) >> 5;                       // query tiles = key tiles (1, or 2 when T = 64)
+    const int bh = blockIdx.x / qt_n, qt = blockIdx.x - bh * qt_n;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Tp = T + 1;                                 // row stride: conflict-free column reads for the P*V operand
+    float *q = lds, *k = q + d * Tp, *v = k + d * Tp;
+    float *xch = v + d * Tp;                              // [4 waves][qt_n * 16 registers][64 lanes]: partial scores
+    // ---- stage the head's q, k, v: all four waves, float4 along the sequence (scalar for odd tiny sequences) -------
+    if (T & 3) {
+        const float *src = qkv + b * qkv_bstride + (long)h * 3 * d * T;
+        for (int e = tid; e < 3 * d * T; e += 256) {
+            const int c = e / T, t = e - c * T;
+            lds[c * Tp + t] = c < 2 * d ? src[e] * scale : src[e];
+        }
+    } else {
+        const f32x4 *src4 = reinterpret_cast<const f32x4 *>(qkv + b * qkv_bstride + (long)h * 3 * d * T);   // head-major [q | k | v]
+        const int vpr = T >> 2, n4 = 3 * d * vpr;
+        for (int e = tid; e < n4; e += 256) {
+            const int c = e / vpr, t4 = e - c * vpr;
+            f32x4 x = src4[e];
+            if (c < 2 * d) { x[0] *= scale; x[1] *= scale; x[2] *= scale; x[3] *= scale; }   // (q * scale), (k * scale) as the reference forms them
+            float *dstp = lds + c * Tp + 4 * t4;
+            dstp[0] = x[0]; dstp[1] = x[1]; dstp[2] = x[2]; dstp[3] = x[3];
         }
     }
     __syncthreads();
+    const int t_glob = qt * 32 + col;                     // this lane's query
+    const bool t_ok = t_glob < T;
+    f32x16 sc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+    // ---- scores, transposed (rows = keys, columns = queries); the channel contraction is split over the waves ----
+    const int cper = ((d / 2 + 3) / 4) * 2;               // channels per wave (even)
+    const int c_beg = wave * cper, c_end = min(d, c_beg + cper);
+    for (int c = c_beg; c < c_end; c += 2) {
+        const float qv = t_ok ? q[(c + half) * Tp + t_glob] : 0.f;                 // B operand: q[c + half][t]
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+            if (kt < qt_n) {
+                const int s_ = kt * 32 + col;
+                const float kv = s_ < T ? k[(c + half) * Tp + s_] : 0.f;         // A operand: k[c + half][s]
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, sc[kt], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+        if (kt < qt_n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[((wave * qt_n + kt) * 16 + r) * 64 + lane] = sc[kt][r];
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+        if (kt < qt_n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t += xch[((w * qt_n + kt) * 16 + r) * 64 + lane];       // fixed order: every wave gets the same bits
+                sc[kt][r] = t;
+            }
+    // ---- softmax over keys: registers of this lane + the partner lane (the other half of the rows) ---------------
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+        if (kt < qt_n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s_ = kt * 32 + frag_row(r, lane);
+                if (s_ >= T) sc[kt][r] = -INFINITY;          // keys beyond the sequence do not exist
+                mx = fmaxf(mx, sc[kt][r]);
+            }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+        if (kt < qt_n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float ex = expf(sc[kt][r] - mx); sc[kt][r] = ex; sum += ex; }
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[kt][r] = sc[kt][r] / sum;
+    // ---- a = v P^T: one 32-channel tile per wave, probabilities from registers ---------------------------------
     float *dst = out + b * out_bstride + (long)h * d * T;
-    for (int e = tid; e < d * T; e += 256) {
-        const int c = e / T, t = e % T;
-        float a = 0.f;
-        for (int s = 0; s < T; ++s) a += w[t * (T + 1) + s] * v[c * T + s];
-        dst[e] = a;
+    for (int c0 = wave * 32; c0 < d; c0 += 128) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int c = c0 + col;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+            if (kt < qt_n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int s_ = kt * 32 + frag_row(r, lane);                  // keys frag_row(r, 0) / frag_row(r, 1)
+                    const float vv = (c < d && s_ < T) ? v[c * Tp + s_] : 0.f;    // A operand: v[c][s]
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[kt][r], acc, 0, 0, 0);
+                }
+        if (t_ok)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = c0 + frag_row(r, lane);
+                if (cr < d) dst[(long)cr * T + t_glob] = acc[r];
+            }
     }
 }
 
@@ -1322,8 +1401,10 @@ static int run_op(surfd_unet *u, const Op &op, const float *x, float *out, int B
     float *o = u->buf_ptr[a.out.buf];
     const long qbs = (long)u->bufs[a.qkv.buf].C * T, obs = (long)u->bufs[a.out.buf].C * T;
     const float scale = 1.f / sqrtf(sqrtf((float)d));
-    const size_t lds_bytes = ((size_t)3 * d * T + (size_t)T * (T + 1)) * sizeof(float);
-    hipLaunchKernelGGL(attn_kernel, dim3(B * heads), dim3(256), lds_bytes, st, qkv, qbs, o, obs, heads, d, T, scale);
+    if (T > 64) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "attention: sequence length %d (at most 64 positions per attention block)", T);
+    const int qtn = (T + 31) / 32;
+    const size_t lds_bytes = ((size_t)3 * d * (T + 1) + (size_t)4 * qtn * 16 * 64) * sizeof(float);
+    hipLaunchKernelGGL(attn_kernel, dim3(B * heads * qtn), dim3(256), lds_bytes, st, qkv, qbs, o, obs, heads, d, T, scale);
     LAUNCH_CHECK();
     return SURFD_OK;
 }
