@@ -744,9 +744,9 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.nby = ceil_div(B, nb);
     // K slices over workgroups when (tiles x batch chunks) under-fills the chip: whole K blocks per slice
     const int nch = c.nblk[0] + (c.nseg > 1 ? c.nblk[1] : 0);
-    static const int ks_fill = env_int("SURFD_CONV2_FILL", 256);       // workgroups aimed at
+    static const int ks_fill = env_int("SURFD_CONV2_FILL", 512);       // workgroups aimed at: two per CU (measured: 1.555 -> 1.472 ms per evaluation)
     static const int ks_max = env_int("SURFD_CONV2_KSMAX", 16);
-    static const int ks_min_base = env_int("SURFD_CONV2_NOSPLIT_ABOVE", 160);
+    static const int ks_min_base = env_int("SURFD_CONV2_NOSPLIT_ABOVE", 200);
     const int base = A.ntiles * A.nby;
     int KS = 1;
     if (base < ks_min_base && nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / base)});
@@ -765,7 +765,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.magic_ks = (unsigned)((0x100000000ULL + KS - 1) / KS);
     const int G = A.ntiles * KS;
     dim3 grid((unsigned)(8 * ceil_div(G, 8) * A.nby));
-    static const int pref = env_int("SURFD_CONV2_PREF", 1);
+    static const int pref = env_int("SURFD_CONV2_PREF", 0);      // operand prefetch across K blocks: measured 1.472 (on) vs 1.442 ms (off) per evaluation
     if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
     else if (pref) hipLaunchKernelGGL((conv2_kernel<8, true>), grid, dim3(256), lds, st, A);
     else hipLaunchKernelGGL((conv2_kernel<8, false>), grid, dim3(256), lds, st, A);
