@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--loop-chains", type=int, default=3,
                     help="with --pipeline 1: reverse loops (of different batches) in flight at once, each on its own stream "
                          "and execution context (MDM.replica)")
+    ap.add_argument("--loop-cus", type=int, default=64,
+                    help="pipeline mode: the CU budget each reverse loop sizes its split-K for (MDM.set_cu_budget); 256 = as if alone")
     ap.add_argument("--unet-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="denoiser conv arithmetic (include/surfd_hip.h: surfd_unet_set_precision)")
     ap.add_argument("--workload", choices=["real", "trace"], default="real",
@@ -283,6 +285,9 @@ def main():
     chains = [model] + [model.replica() for _ in range(max(1, a.loop_chains) - 1)] if a.pipeline else [model]
     for m in chains[1:]:
         m.set_precision(a.unet_precision)
+    if a.pipeline:
+        for m in chains:
+            m.set_cu_budget(a.loop_cus)
 
     def sample_latents(chain=0):
         return diffusion.p_sample_loop(chains[chain], (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}},
@@ -332,6 +337,9 @@ def main():
         prof[name] = (n.value, ms.value)
     # ---- untimed extras: workload counters (deterministic), one loop alone, the trace workload -------------
     dec.set_grid_blocks(0)
+    if a.pipeline and a.loop_cus != 256:
+        model.set_cu_budget(256)                         # one loop alone owns the chip
+        sample_latents()                                 # re-capture outside the timed call
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     lat = sample_latents()
@@ -397,7 +405,7 @@ def main():
                    "decoder_precision": a.decoder_precision, "unet_precision": a.unet_precision,
                    "fp16_range_saturations": sat,
                    "pipeline": (f"{len(chains)} reverse loops of different batches in flight (own stream + context each) next to the "
-                                f"grids of an older batch; the decoder kernels run on {a.decoder_blocks} of the 256 CUs while loops "
+                                f"grids of an older batch (each loop sizes its split-K for {a.loop_cus} CUs); the decoder kernels run on {a.decoder_blocks} of the 256 CUs while loops "
                                 "are in flight and on all of them for the last batch; every batch runs start to finish inside the "
                                 "timed region") if a.pipeline else "none (loop then grids, one stream)",
                    "parallelism": f"shape-parallel x{world}, no data-path collective (latents all_gathered after the timed region)"},
@@ -411,7 +419,7 @@ def main():
                      "issued_tflops": (3.0 if f16 else 1.0) * algorithmic, "issued_frac": (3.0 if f16 else 1.0) * algorithmic / peak,
                      "cus": (f"{a.decoder_blocks} of 256 while loops are in flight, 256 for the last batch; peak is the whole chip's")
                             if a.pipeline else "256"},
-        "roofline_loop": {"kernel": "conv2_kernel<8,true> x84 + attn_kernel x16 per denoiser evaluation (hipGraph replay)",
+        "roofline_loop": {"kernel": "conv2_kernel<8,false> x84 + attn_kernel x16 per denoiser evaluation (hipGraph replay)",
                           "bound": "hbm", "achieved": streamed_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": streamed_gbs / HBM_PEAK_GBS,
                           "traffic": (pmc or {}).get("unet_eval_hbm_bytes"),

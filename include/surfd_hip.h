@@ -92,6 +92,12 @@ int surfd_unet_forward(surfd_unet *u, const float *x, const int64_t *t, const fl
  *     counted (surfd_unet_saturation_count).  0 = "fp32": exact v_mfma_f32_32x32x2_f32, no range limit.
  * The initial mode can also be set with SURFD_UNET_PRECISION=fp32|f16x2. */
 int surfd_unet_set_precision(surfd_unet *u, int mode);
+/* How many CUs this handle's launches can count on (default 256 = the whole chip).  The conv kernel splits the
+ * contraction of small layers over extra workgroups until about two per CU are in flight; a handle that shares the
+ * chip (several loops next to the decoder, surfd_amd.parallel.BatchPipeline) is told its share so that it does not
+ * pay the split's redundant operand staging for parallelism it cannot get.  Results for different budgets differ in
+ * fp32 summation order only.  No reference counterpart. */
+int surfd_unet_set_cu_budget(surfd_unet *u, int cus);
 /* host-sync: number of workgroups of the f16x2 conv kernel that had to clamp an operand to the fp16 range since the
  * last reset (0 = every evaluation so far was inside the range the mode is exact for) */
 int surfd_unet_saturation_count(surfd_unet *u, int reset, int64_t *count, surfd_stream s);

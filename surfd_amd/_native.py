@@ -52,6 +52,7 @@ _SIGS = {
     "surfd_unet_finalize": (C.c_int, [_P, _P]),
     "surfd_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "surfd_unet_set_precision": (C.c_int, [_P, C.c_int]),
+    "surfd_unet_set_cu_budget": (C.c_int, [_P, C.c_int]),
     "surfd_unet_saturation_count": (C.c_int, [_P, C.c_int, c_i64p, _P]),
     "surfd_unet_debug_only_op": (C.c_int, [_P, C.c_int]),
     "surfd_unet_debug_run_module": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -744,7 +744,8 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.nby = ceil_div(B, nb);
     // K slices over workgroups when (tiles x batch chunks) under-fills the chip: whole K blocks per slice
     const int nch = c.nblk[0] + (c.nseg > 1 ? c.nblk[1] : 0);
-    static const int ks_fill = env_int("SURFD_CONV2_FILL", 512);       // workgroups aimed at: two per CU (measured: 1.555 -> 1.472 ms per evaluation)
+    static const int ks_fill_env = env_int("SURFD_CONV2_FILL", 0);
+    const int ks_fill = ks_fill_env ? ks_fill_env : 2 * u->cu_budget;  // workgroups aimed at: two per CU (measured: 1.555 -> 1.472 ms per evaluation)
     static const int ks_max = env_int("SURFD_CONV2_KSMAX", 16);
     static const int ks_min_base = env_int("SURFD_CONV2_NOSPLIT_ABOVE", 200);
     const int base = A.ntiles * A.nby;

@@ -1481,6 +1481,12 @@ extern "C" int surfd_unet_set_precision(surfd_unet *u, int mode) {
     return SURFD_OK;
 }
 
+extern "C" int surfd_unet_set_cu_budget(surfd_unet *u, int cus) {
+    if (!u || cus < 1 || cus > 256) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_cu_budget: need 1 <= cus <= 256");
+    if (u->cu_budget != cus) { u->cu_budget = cus; u->ws_gen++; }      // captured loop graphs hold the old launch shapes
+    return SURFD_OK;
+}
+
 // developer aid: op >= 0 restricts the f16x2 kernel to that one conv op (all others run exact fp32), -1 lifts it
 extern "C" int surfd_unet_debug_only_op(surfd_unet *u, int op) {
     if (!u) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_debug_only_op: null handle");

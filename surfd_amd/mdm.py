@@ -111,6 +111,12 @@ class MDM(nn.Module):
         L, h = self._native()
         N.check(L.surfd_unet_set_precision(h, {"fp32": 0, "f16x2": 1}[mode]))
 
+    def set_cu_budget(self, cus: int) -> None:
+        """Tell this execution context how many CUs its launches can count on (256 = whole chip, the default): sizes
+        the conv kernel's split-K.  Set by throughput pipelines that run several loops next to the decoder."""
+        L, h = self._native()
+        N.check(L.surfd_unet_set_cu_budget(h, int(cus)))
+
     def saturation_count(self, reset: bool = True) -> int:
         """Workgroups of the f16x2 conv kernel that clamped an operand to +-65504 since the last reset; a non-zero
         value means this checkpoint leaves the range the mode is exact for -> use set_precision('fp32')."""

@@ -377,6 +377,31 @@ def test_unet_precision_modes_agree():
     assert model.saturation_count() == 0
 
 
+def test_cu_budget_changes_summation_order_only():
+    """MDM.set_cu_budget sizes the split-K of the convs (a loop that shares the chip gets fewer, larger workgroups): the
+    forward agrees with the default to fp32 rounding, a cached loop graph is re-captured, and restoring the budget
+    restores the bits."""
+    model, _, _ = _model("no_cond")
+    _, dd, _ = _model("no_cond", "ddim10")
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(8, 1, 32, generator=g).cuda()
+    t = torch.randint(0, 1000, (8,), generator=g).cuda()
+    noise = synth.synth_noise_batch(10, 0, 8, 32).cuda()
+    run = lambda: dd.ddim_sample_loop(model, (8, 1, 32), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise, fused=True).clone()
+    a, la = model(x, t, y={}).clone(), run()
+    try:
+        for cus in (16, 64):
+            model.set_cu_budget(cus)
+            b, lb = model(x, t, y={}).clone(), run()
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+            assert float((la - lb).abs().max()) <= 1e-4
+    finally:
+        model.set_cu_budget(256)
+    assert torch.equal(model(x, t, y={}), a) and torch.equal(run(), la)
+    with pytest.raises(RuntimeError):
+        model.set_cu_budget(0)
+
+
 def test_unet_saturation_is_counted():
     """Operands beyond the fp16 range are clamped by the f16x2 convs and MUST be reported (never silent)."""
     model, _, _ = _model("no_cond")
