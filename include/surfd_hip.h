@@ -254,6 +254,27 @@ void surfd_mc_destroy(surfd_mc *m);
 int surfd_mc_lut_count(void);
 int surfd_mc_lut(int i, const char **name, const signed char **values, int *ndim, int dims[3]);
 
+/* ------------------------------------------------------------------------------------ */
+/* CrossAttention over [b, n, c] tokens (modules/attention.py:152-193) — SURVEY §8 a19.  */
+/* No Surf-D configuration instantiates the module (use_spatial_transformer is False);    */
+/* a standalone op with its own handle, fp32 on the matrix pipe.                           */
+/* ------------------------------------------------------------------------------------ */
+typedef struct surfd_xattn surfd_xattn;
+/* CrossAttention.__init__(query_dim, context_dim=None, heads=8, dim_head=64) (:153-169); context_dim <= 0 means
+ * "same as query_dim".  dim_head <= 128. */
+int surfd_xattn_create(int query_dim, int context_dim, int heads, int dim_head, surfd_xattn **out);
+void surfd_xattn_destroy(surfd_xattn *a);
+/* state_dict entries of the reference module, fp32 device pointers: "to_q.weight" [heads*dim_head, query_dim],
+ * "to_k.weight" / "to_v.weight" [heads*dim_head, context_dim], "to_out.0.weight" [query_dim, heads*dim_head],
+ * "to_out.0.bias" [query_dim] */
+int surfd_xattn_set_param(surfd_xattn *a, const char *name, const float *src, const int64_t *shape, int ndim, surfd_stream s);
+/* CrossAttention.forward(x, context=None, mask=None) (:171-193): x [B, N, query_dim]; context [B, M, context_dim] or
+ * NULL (self-attention, M ignored); mask [B, M] bytes, non-zero = attend, or NULL (masked scores are set to
+ * -FLT_MAX exactly as masked_fill_ does, so a fully masked row attends uniformly); out [B, N, query_dim].
+ * Dropout (p = 0 in every constructor call of the reference) is the identity. */
+int surfd_xattn_forward(surfd_xattn *a, const float *x, const float *context, const unsigned char *mask, float *out,
+                        int B, int N, int M, surfd_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,10 @@ _SIGS = {
     "surfd_mc_num_faces": (C.c_int64, [_P]),
     "surfd_mc_copy": (C.c_int, [_P, _P, _P, _P, _P]),
     "surfd_mc_destroy": (None, [_P]),
+    "surfd_xattn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "surfd_xattn_destroy": (None, [_P]),
+    "surfd_xattn_set_param": (C.c_int, [_P, C.c_char_p, _P, c_i64p, C.c_int, _P]),
+    "surfd_xattn_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "surfd_mc_lut_count": (C.c_int, []),
     "surfd_mc_lut": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_byte)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

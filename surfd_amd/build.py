@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsurfd_hip.so")
-SOURCES = ["core.hip", "decoder.hip", "grid.hip", "unet.hip", "conv_f16x2.hip", "sampler.hip", "mcubes.cpp"]   # .cpp = host-only code
+SOURCES = ["core.hip", "decoder.hip", "grid.hip", "unet.hip", "conv_f16x2.hip", "sampler.hip", "xattn.hip", "mcubes.cpp"]   # .cpp = host-only code
 # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so with the default
 # "fast" contraction the compiler would fuse the separately rounded steps that mirror torch's
 # fp32 op sequence (grid coordinates, posterior updates) into FMAs.

@@ -82,6 +82,14 @@ def synth_decoder_state_dict(cfg: DecoderConfig = DecoderConfig(), seed: int = 0
     return sd
 
 
+def synth_cross_attention_state_dict(query_dim: int, context_dim: int, heads: int, dim_head: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Deterministic weights in the state_dict layout of the reference's CrossAttention (modules/attention.py:161-169)."""
+    inner = heads * dim_head
+    shapes = {"to_q.weight": (inner, query_dim), "to_k.weight": (inner, context_dim), "to_v.weight": (inner, context_dim),
+              "to_out.0.weight": (query_dim, inner), "to_out.0.bias": (query_dim,)}
+    return {k: _normal(s, 0.1 if k.endswith("bias") else 1.5 / s[-1] ** 0.5, "xattn." + k, seed) for k, s in shapes.items()}
+
+
 def synth_noise(num_steps: int, sample_index: int, latent_len: int, seed: int = 1234) -> torch.Tensor:
     """Noise stream of ONE sample: row 0 is x_T, row 1+k is the z drawn at loop step k.
 

@@ -458,6 +458,42 @@ def g13_marching_cubes(R, with_512: bool):
     save("g13_marching_cubes", **out)
 
 
+XATTN_CASES = [   # name, query_dim, context_dim (None: self), heads, dim_head, b, n, m, masked
+    ("self_small", 64, None, 4, 32, 2, 48, 48, False),
+    ("cross_ldm", 320, 512, 8, 64, 3, 32, 77, True),            # LDM's usual text-conditioning shape
+    ("ragged", 96, 40, 3, 20, 2, 37, 5, True),                 # nothing a multiple of the tile sizes; one sample fully masked
+    ("single", 32, 16, 1, 8, 1, 1, 1, False),
+    ("long_ctx", 128, 128, 2, 128, 1, 130, 200, False),
+]
+
+
+def g14_cross_attention(R):
+    """a19: the reference's CrossAttention module itself on seeded inputs."""
+    from modules import attention as ratt
+    out = {}
+    for name, qd, cd, heads, dh, b, n, m, masked in XATTN_CASES:
+        mod = ratt.CrossAttention(qd, cd, heads=heads, dim_head=dh).eval()
+        sd = synth.synth_cross_attention_state_dict(qd, cd or qd, heads, dh, seed=len(name))
+        mod.load_state_dict(sd, strict=True)
+        x = rnd((b, n, qd), 1400 + len(name))
+        ctx = None if cd is None else rnd((b, m, cd), 1500 + len(name))
+        mask = None
+        if masked:
+            g = torch.Generator().manual_seed(1600 + len(name))
+            mask = torch.rand(b, m, generator=g) > 0.3
+            mask[-1] = False                                   # a fully masked sample: uniform attention
+        with torch.no_grad():
+            y = mod(x, context=ctx, mask=mask)
+        out[name + "__cfg"] = np.array([qd, cd or 0, heads, dh, len(name)])      # sizes + the weight seed
+        out[name + "__x"] = x
+        out[name + "__out"] = y
+        if ctx is not None:
+            out[name + "__context"] = ctx
+        if mask is not None:
+            out[name + "__mask"] = mask
+    save("g14_cross_attention", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -470,7 +506,7 @@ def main():
     jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
             "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
             "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R),
-            "g13": lambda: g13_marching_cubes(R, a.mc512)}
+            "g13": lambda: g13_marching_cubes(R, a.mc512), "g14": lambda: g14_cross_attention(R)}
     only = [s for s in a.only.split(",") if s]
     for name, fn in jobs.items():
         if only and name not in only:
