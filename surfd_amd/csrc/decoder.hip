@@ -74,13 +74,15 @@ constexpr int KS_E = 4;                       // k16 steps of the 64-deep first 
 constexpr size_t HF_FCP = (size_t)16 * KS_E * 2 * 64 * 8;     // fp16 elements
 constexpr size_t HF_HH = (size_t)16 * KS_H * 2 * 64 * 8;
 __host__ __device__ constexpr size_t hf_off_fc(int k, int which) { return HF_FCP + (size_t)(2 * k + which) * HF_HH; }
-constexpr size_t WHF_ELEMS = HF_FCP + (size_t)2 * NB * HF_HH;
+// transposed hidden matrices (reverse sweep in f16x2): same fragment layout and k-slot order, after the forward ones
+__host__ __device__ constexpr size_t hf_off_fcT(int k, int which) { return HF_FCP + (size_t)(2 * NB + 2 * k + which) * HF_HH; }
+constexpr size_t WHF_ELEMS = HF_FCP + (size_t)4 * NB * HF_HH;
 constexpr int VOFF_SC = VOFF_BOUT + 1;        // SC, 1/SC (floats) and max|W| bits, after b_out
 __host__ __device__ constexpr int slot_channel(int s) { return 128 * (s >> 7) + 64 * ((s >> 6) & 1) + 32 * (s & 1) + ((s >> 1) & 31); }
 
 struct DecParams {
     const float *wpack;   // WPACK_FLOATS
-    const _Float16 *whf;  // WHF_ELEMS (f16x2 forward path only)
+    const _Float16 *whf;  // WHF_ELEMS (f16x2 kernels only)
     const float *vecs;    // VEC_FLOATS: biases, w_out, b_out
     const float *tab;     // this sample's [NCBN][2][H] scale/shift
     int input_dim;
@@ -275,7 +277,6 @@ __device__ long long g_dec_stamps[8];
 
 template <bool GRAD, bool F16X2 = false>
 __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
-    static_assert(!(GRAD && F16X2), "the reverse sweep is fp32 only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X = lds;                      // [TP][XS]
     float *E = lds;                      // [TP][ES] first-layer input, aliases X (dead before X is written)
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     float *LOG = PT + TP * 4;            // [TP]
     float *E2 = LOG + TP;                // [TP][ES] d logit / d enc          (GRAD only)
     float *DV = E2 + TP * ES;            // [TP][4]  d logit / d xyz          (GRAD only)
+    float *RED = DV + TP * 4;            // [4] per-wave maxima of the adjoint   (GRAD && F16X2 only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     // Scalar fp32 ops on purpose: packed-f32 ops would need register pairs built from two accumulator
     // tiles (copies + spills), and this mode has no bitwise contract, so the affine map is one fma.
     int sat_flag = 0;      // wave-uniform: some lane of this wave produced an activation beyond the fp16 range (f16x2 mode)
-    auto store_split = [&](const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4]) {
+    auto store_split = [&](const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4], unsigned *mk = nullptr) {
         float umax = 0.f;  // local to one epilogue: a value kept across the GEMM loops would cost spills in the hot loop
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -314,6 +316,10 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                     const float t0 = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]);
                     const float t1 = __builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r], sb[2 * q + 1]);
                     umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));          // one v_max3_f32: range accounting
+                    if constexpr (GRAD) {                                           // ReLU gates for the reverse sweep
+                        if (t0 > 0.f) mk[mword(mt, 2 * q)] |= 1u << mbit(mt, 2 * q, r);
+                        if (t1 > 0.f) mk[mword(mt, 2 * q + 1)] |= 1u << mbit(mt, 2 * q + 1, r);
+                    }
                     const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
                     const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
                     const f32x2 u = {u0, u1};
@@ -461,7 +467,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                 for (int nt = 0; nt < 4; ++nt) { sa[nt] = nsa[nt]; sb[nt] = nsb[nt]; }
                 if constexpr (GRAD) { msk[2 * k][0] = msk[2 * k][1] = msk[2 * k][2] = msk[2 * k][3] = 0u; }
                 if constexpr (F16X2) {
-                    store_split(net, sa, sb);
+                    unsigned *mk = nullptr;
+                    if constexpr (GRAD) mk = msk[2 * k];
+                    store_split(net, sa, sb, mk);
                 } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -501,7 +509,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                     float sbb[4];      // a*(t + bias) + b = a*t + (a*bias + b)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) sbb[nt] = __builtin_fmaf(sa[nt], bias[nt], sb[nt]);
-                    store_split(tmp, sa, sbb);
+                    unsigned *mk = nullptr;
+                    if constexpr (GRAD) mk = msk[2 * k + 1];
+                    store_split(tmp, sa, sbb, mk);
                 } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -529,6 +539,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             if constexpr (F16X2) {
                 if (k + 1 < NB) gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
                                                            whf + hf_off_fc(k + 1 < NB ? k + 1 : 0, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, net, lane);
+                else if constexpr (GRAD) gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
+                                                whf + hf_off_fcT(NB - 1, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, net, lane);   // first matrix of the reverse sweep
                 else gemm_2x4_f16x2<KS_H, KS_E>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
                                                 whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, ws, net, lane);     // next tile's fc_p
             }
@@ -620,7 +632,93 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        g[mt][nt][r] = ((msk[2 * NB][mword(mt, nt)] >> mbit(mt, nt, r)) & 1u) ? wo[nt] * a10[nt] : 0.f;
+                        g[mt][nt][r] = ((msk[2 * NB][mword(mt, nt)] >> mbit(mt, nt, r)) & 1u) ? scl(wo[nt] * a10[nt], wsc) : 0.f;   // a10 carries 1/SC in f16x2 mode
+            if constexpr (F16X2) {
+                // The adjoint has no natural range (unlike post-ReLU activations), so every operand tile is brought to
+                // [2^14, 2^15) by ONE power of two per 64-point tile before it is split: rows are independent, the
+                // factor is exact, the accumulators stay fp32, and it is divided out in the next epilogue.  The maximum
+                // goes through LDS between the two barriers every GEMM needs anyway.
+                auto lane_absmax = [&](const f32x16 (&v)[2][4]) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; r += 2)
+                                m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[mt][nt][r]), __builtin_fabsf(v[mt][nt][r + 1])));
+                    return m;
+                };
+                // -> (s, 1/s); contains the barrier that also retires the previous GEMM's readers of X
+                auto tile_scale = [&](float m, float &inv) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+                    if (lane == 0) RED[wave] = m;
+                    __syncthreads();
+                    const float t = __builtin_fmaxf(__builtin_fmaxf(RED[0], RED[1]), __builtin_fmaxf(RED[2], RED[3]));
+                    const int e = (int)(__float_as_uint(t) >> 23);                 // biased exponent of the tile maximum
+                    const int se = (e == 0 || e == 255) ? 127 : min(max(268 - e, 4), 250);
+                    inv = __uint_as_float((unsigned)(254 - se) << 23);
+                    return __uint_as_float((unsigned)se << 23);
+                };
+                auto store_split_scaled = [&](const f32x16 (&v)[2][4], float s) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const f32x2 u = {v[mt][2 * q][r] * s, v[mt][2 * q + 1][r] * s};
+                                unsigned hi, lo;
+                                split2(u, hi, lo);
+                                XW(mt, q, r, 0) = hi;
+                                XW(mt, q, r, 1) = lo;
+                            }
+                };
+#pragma unroll
+                for (int k = NB - 1; k >= 0; --k) {
+                    float inv_s;
+                    const float s1 = tile_scale(lane_absmax(g), inv_s);
+                    store_split_scaled(g, s1);                                       // X <- g
+                    float f1[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) f1[nt] = tab[(2 * k + 1) * 2 * H + cb + 32 * nt] * (winv * inv_s);
+                    __syncthreads();
+                    zero_acc(tmp);
+                    gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fcT(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
+                                               whf + hf_off_fcT(k, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, tmp, lane);   // t = fc_1^T g
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const bool on = (msk[2 * k + 1][mword(mt, nt)] >> mbit(mt, nt, r)) & 1u;
+                                tmp[mt][nt][r] = on ? tmp[mt][nt][r] * f1[nt] : 0.f;
+                            }
+                    const float s0 = tile_scale(lane_absmax(tmp), inv_s);
+                    store_split_scaled(tmp, s0);
+                    float f0[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) f0[nt] = tab[(2 * k) * 2 * H + cb + 32 * nt] * (winv * inv_s);
+                    __syncthreads();
+                    zero_acc(tmp);
+                    if (k > 0) gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fcT(k, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
+                                                          whf + hf_off_fcT(k > 0 ? k - 1 : 0, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, tmp, lane);   // fc_0^T t
+                    else gemm_2x4_f16x2<KS_H, KS_E>(X, whf + hf_off_fcT(k, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
+                                                    whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, ws, tmp, lane);                 // then the next tile's fc_p
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const bool on = (msk[2 * k][mword(mt, nt)] >> mbit(mt, nt, r)) & 1u;
+                                g[mt][nt][r] += on ? tmp[mt][nt][r] * f0[nt] : 0.f;
+                            }
+                }
+                __syncthreads();       // the last GEMM's readers of X are done
+            } else {
 #pragma unroll
             for (int k = NB - 1; k >= 0; --k) {
                 // X <- g
@@ -667,6 +765,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
                             }
                 }
                 __syncthreads();
+            }
             }
             // X <- g ; e2 = fc_p^T g  (64 x 64)
 #pragma unroll
@@ -731,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 
 #undef XAT
 #undef XW
-constexpr size_t DEC_LDS_BYTES = (size_t)(TP * XS + TP * 4 + TP + TP * ES + TP * 4) * sizeof(float);
+constexpr size_t DEC_LDS_BYTES = (size_t)(TP * XS + TP * 4 + TP + TP * ES + TP * 4 + 4) * sizeof(float);
 
 // ---------------------------------------------------------------------------------------------
 // per-sample conditional-BN tables
@@ -873,6 +972,8 @@ static int dec_alloc(surfd_decoder *d) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
     d->allocated = true;
     return SURFD_OK;
@@ -1017,6 +1118,9 @@ int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s) {
             hipLaunchKernelGGL(pack_f16x2_kernel, dim3(1024), dim3(256), 0, st, d->wpack + off_fc(k, which), KG_H, KS_H, 1,
                                d->vecs + VOFF_SC, d->whf + hf_off_fc(k, which));
             LAUNCH_CHECK();
+            hipLaunchKernelGGL(pack_f16x2_kernel, dim3(1024), dim3(256), 0, st, d->wpack + off_fcT(k, which), KG_H, KS_H, 1,
+                               d->vecs + VOFF_SC, d->whf + hf_off_fcT(k, which));
+            LAUNCH_CHECK();
         }
     d->finalized = true;
     return SURFD_OK;
@@ -1096,7 +1200,9 @@ int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles
     long blocks = d->grid_blocks > 0 ? std::min(d->grid_blocks, d->num_cus) : d->num_cus;
     if (ntiles_hint >= 0) blocks = std::min<long>(blocks, std::max<long>(ntiles_hint, 1));
     hipEvent_t prof_ev = prof_begin(grad ? PROF_DEC_GRAD : PROF_DEC_FWD, st);
-    if (grad)
+    if (grad && d->precision == 1)
+        hipLaunchKernelGGL((decoder_kernel<true, true>), dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
+    else if (grad)
         hipLaunchKernelGGL(decoder_kernel<true>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     else if (d->precision == 1)
         hipLaunchKernelGGL((decoder_kernel<false, true>), dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
