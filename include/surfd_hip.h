@@ -156,14 +156,17 @@ int surfd_decoder_param_info(const surfd_decoder *d, int i, const char **key, in
 int surfd_decoder_set_param(surfd_decoder *d, const char *key, const void *dev_ptr,
                             const int64_t *shape, int ndim, surfd_stream s);
 int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s);
-/* Arithmetic of the FORWARD decoder kernel (udf / logits / grid fill):
+/* Arithmetic of the decoder kernels (udf / logits / grid fill, and the forward + reverse sweep of
+ * surfd_decoder_udf_grad):
  * 1 = "f16x2" (default): every fp32 operand is split into two fp16 terms (weights pre-scaled by one power
  *     of two), the three significant products are accumulated in fp32 on the fp16 matrix pipe.  Error
  *     against an fp64 evaluation is the same size as the plain fp32 kernel's (tests/test_gpu_decoder_grid.py);
  *     activations saturate at 65504.  2.85x the throughput of mode 0 on MI355X.
  * 0 = "fp32": v_mfma_f32_32x32x2_f32, bitwise an fmaf chain, no range limit.
- * The gradient kernel (surfd_decoder_udf_grad) always runs in fp32.  The initial mode can also be set with
- * SURFD_DECODER_PRECISION=fp32|f16x2. */
+ * In mode 1 the reverse sweep scales the adjoint of each 64-point tile by one power of two before the fp16 split
+ * (exact, divided out afterwards; no range limit): directions agree with mode 0 to the golden tolerance, but a point's
+ * last bits can depend on the points it shares a tile with; mode 0 is bitwise independent of the tiling.
+ * The initial mode can also be set with SURFD_DECODER_PRECISION=fp32|f16x2. */
 int surfd_decoder_set_precision(surfd_decoder *d, int mode);
 /* host-sync: waves of the f16x2 forward kernel that produced an activation beyond +-65504 (clamped) since the last
  * reset.  Non-zero = this checkpoint / latent leaves the range mode 1 is exact for: switch to mode 0. */

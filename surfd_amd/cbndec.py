@@ -170,8 +170,8 @@ class CbnDecoder(nn.Module):
         return L, self._handle
 
     def set_precision(self, mode: str) -> None:
-        """Forward-kernel arithmetic: 'f16x2' (default: split-fp16 on the fp16 matrix pipe, fp32-class accuracy,
-        see csrc/decoder.hip) or 'fp32' (exact fp32 MFMA)."""
+        """Arithmetic of the forward and the gradient kernel: 'f16x2' (default: split-fp16 on the fp16 matrix pipe,
+        fp32-class accuracy, see csrc/decoder.hip) or 'fp32' (exact fp32 MFMA, bitwise independent of the tiling)."""
         L, h = self._native()
         N.check(L.surfd_decoder_set_precision(h, {"fp32": 0, "f16x2": 1}[mode]))
 

@@ -52,7 +52,7 @@ constexpr int VOFF_WOUT = H * (1 + 2 * NB);
 constexpr int VOFF_BOUT = H * (2 + 2 * NB);
 constexpr int VEC_FLOATS = VOFF_BOUT + 4;
 
-// ---- optional "f16x2" forward path (surfd_decoder_set_precision / SURFD_DECODER_PRECISION=f16x2) -----
+// ---- "f16x2" arithmetic (default; surfd_decoder_set_precision / SURFD_DECODER_PRECISION) -----------------
 // Every fp32 operand is split into two fp16 terms, x = xh + xl with |x - xh - xl| <= 2^-22 |x|, and the
 // three products xh*wh + xh*wl + xl*wh are accumulated in fp32 on the fp16 matrix pipe
 // (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate): 16/3 = 5.3x the fp32 matrix rate at fp32-class
@@ -63,7 +63,9 @@ constexpr int VEC_FLOATS = VOFF_BOUT + 4;
 //    X is [256 words of high halves][256 words of low halves][4 pad], word w = two consecutive k-slots;
 //    k-slot order is chosen so that the epilogue's natural register pairs are the two halves of a word:
 //        slot s -> channel 128*(s>>7) + 64*((s>>6)&1) + 32*(s&1) + ((s>>1)&31)
-//  * activations saturate at 65504 (fp16 max) in this mode; the fp32 path has no such limit.
+//  * activations saturate at 65504 (fp16 max) in this mode (counted in DecParams.sat); the fp32 path has no such limit;
+//  * the reverse sweep uses the same machinery with the transposed matrices; its operand (the adjoint, no natural
+//    range) is scaled per 64-point tile by one power of two so that the tile maximum lands in [2^14, 2^15).
 // Weight planes, fragment-major for the 32x32x16 MFMA:
 //   whf[(((tile*KS + ks)*2 + plane)*64 + lane)*8 + e] = plane(SC * W[tile*32 + (lane&31)][chan(ks*16 + 8*(lane>>5) + e)])
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -310,26 +312,61 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt) {
+                if constexpr (!GRAD) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t0 = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]);
-                    const float t1 = __builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r], sb[2 * q + 1]);
-                    umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));          // one v_max3_f32: range accounting
-                    if constexpr (GRAD) {                                           // ReLU gates for the reverse sweep
-                        if (t0 > 0.f) mk[mword(mt, 2 * q)] |= 1u << mbit(mt, 2 * q, r);
-                        if (t1 > 0.f) mk[mword(mt, 2 * q + 1)] |= 1u << mbit(mt, 2 * q + 1, r);
+                    for (int r = 0; r < 16; ++r) {
+                        const float t0 = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]);
+                        const float t1 = __builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r], sb[2 * q + 1]);
+                        umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));          // one v_max3_f32: range accounting
+                        const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
+                        const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
+                        const f32x2 u = {u0, u1};
+                        const f16x2 h = __builtin_convertvector(u, f16x2);              // one v_cvt_pk_f16_f32
+                        const f32x2 hf = __builtin_convertvector(h, f32x2);
+                        const f32x2 rr = {u0 - hf.x, u1 - hf.y};
+                        const f16x2 l = __builtin_convertvector(rr, f16x2);
+                        XW(mt, q, r, 0) = __builtin_bit_cast(unsigned, h);
+                        XW(mt, q, r, 1) = __builtin_bit_cast(unsigned, l);
                     }
-                    const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
-                    const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
-                    const f32x2 u = {u0, u1};
-                    const f16x2 h = __builtin_convertvector(u, f16x2);              // one v_cvt_pk_f16_f32
-                    const f32x2 hf = __builtin_convertvector(h, f32x2);
-                    const f32x2 rr = {u0 - hf.x, u1 - hf.y};
-                    const f16x2 l = __builtin_convertvector(rr, f16x2);
-                    XW(mt, q, r, 0) = __builtin_bit_cast(unsigned, h);
-                    XW(mt, q, r, 1) = __builtin_bit_cast(unsigned, l);
+                    continue;
                 }
+                // gradient kernel (more live state: gates, both accumulators): one accumulator-tile pair at a time bounds
+                // the live ranges, and four independent value pairs are processed stage by stage (measured +6 %)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 4) {
+                    float t0[4], t1[4];
+                    f32x2 u[4], rr[4];
+                    f16x2 h[4], l[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        t0[i] = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r0 + i], sb[2 * q]);
+                        t1[i] = __builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r0 + i], sb[2 * q + 1]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0[i], t1[i]));      // one v_max3_f32: range accounting
+                        if constexpr (GRAD) {                                             // ReLU gates for the reverse sweep
+                            if (t0[i] > 0.f) mk[mword(mt, 2 * q)] |= 1u << mbit(mt, 2 * q, r0 + i);
+                            if (t1[i] > 0.f) mk[mword(mt, 2 * q + 1)] |= 1u << mbit(mt, 2 * q + 1, r0 + i);
+                        }
+                        u[i].x = __builtin_amdgcn_fmed3f(t0[i], 0.f, 65504.f);
+                        u[i].y = __builtin_amdgcn_fmed3f(t1[i], 0.f, 65504.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = __builtin_convertvector(u[i], f16x2);      // one v_cvt_pk_f16_f32
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rr[i] = u[i] - __builtin_convertvector(h[i], f32x2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) l[i] = __builtin_convertvector(rr[i], f16x2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        XW(mt, q, r0 + i, 0) = __builtin_bit_cast(unsigned, h[i]);
+                        XW(mt, q, r0 + i, 1) = __builtin_bit_cast(unsigned, l[i]);
+                    }
+                }
+            }
         sat_flag |= __any(umax > 65504.f);
     };
 
