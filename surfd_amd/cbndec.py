@@ -136,11 +136,23 @@ class CbnDecoder(nn.Module):
         self._handle = None
         self._bound_key = None          # (device, versions) the native copy was made from
         self._latents_key = None
+        self._key_tensors = None
 
     # ---- native handle management -------------------------------------------------------------
     def _state_key(self):
-        sd = self.state_dict(keep_vars=True)
-        return tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        # the tensor objects are collected once (rebuilding a 101-entry state_dict on every udf call is measurable in
+        # callback mode); .to()/.cuda() replace buffer objects and load_state_dict may too, so both drop the list
+        if self._key_tensors is None:
+            self._key_tensors = [v for _, v in self.state_dict(keep_vars=True).items()]
+        return tuple((v.data_ptr(), v._version) for v in self._key_tensors)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._key_tensors = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._key_tensors = None
+        return super().load_state_dict(*args, **kwargs)
 
     def _native(self):
         first = next(self.parameters())
@@ -198,10 +210,10 @@ class CbnDecoder(nn.Module):
         self._keepalive = lat
 
     def _bind_single(self, lat: Tensor) -> int:
-        key = (lat.data_ptr(), lat._version, 1, "single")
-        if self._latents_key != key:
-            self.bind_latents(lat.reshape(1, -1))
-            self._latents_key = key
+        # always rebind: writes by native kernels (a sampling loop's output, gather buffers) do not bump a tensor's
+        # version counter, so (address, version) cannot prove the contents are the ones the tables were built from;
+        # the table kernel is one tiny launch
+        self.bind_latents(lat.reshape(1, -1))
         return 0
 
     # ---- kernels ---------------------------------------------------------------------------------

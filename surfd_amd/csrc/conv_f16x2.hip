@@ -732,7 +732,8 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.bias = u->vecs + c.bias_off;
     A.emb = A.bias; A.emb_bstride = 0; A.res = A.bias; A.res_bstride = 0; A.res_cstride = 1; A.res_lstride = 0;
     if (c.emb_off >= 0 && io.emb) {
-        A.emb = io.emb + c.emb_off; A.emb_bstride = io.emb_bs; A.step_ptr = io.step_ptr; A.emb_step_stride = (long)B * io.emb_bs;
+        A.emb = io.emb + c.emb_off; A.step_ptr = io.step_ptr;
+        A.emb_bstride = u->emb_shared ? 0 : io.emb_bs; A.emb_step_stride = u->emb_shared ? io.emb_bs : (long)B * io.emb_bs;
         A.has_emb = 1;
     }
     if (c.res.buf != -1) {

@@ -145,10 +145,14 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     hipEvent_t prof_ev = prof_begin(PROF_LOOP, st);
     // every timestep-only quantity of the denoiser for all T' iterations at once: loop
     // iteration k runs original timestep timestep_map[T'-1-k] for every sample
-    std::vector<int64_t> t_rows((size_t)T * B);
+    // (one row per step when nothing but t enters the embedding, else one per (step, sample): T' x B x 14112 floats)
+    const bool shared = !ctx && !cls;
+    const int per_step = shared ? 1 : B;
+    if ((long)T * per_step > 2000000) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "surfd_sample_loop: %d steps x %d samples of embedding rows", T, per_step);
+    std::vector<int64_t> t_rows((size_t)T * per_step);
     for (int k = 0; k < T; ++k)
-        for (int b = 0; b < B; ++b) t_rows[(size_t)k * B + b] = cfg->timestep_map[T - 1 - k];
-    int rc = unet_prepare_embeddings(u, t_rows.data(), T * B, ctx, cls, B, st);
+        for (int b = 0; b < per_step; ++b) t_rows[(size_t)k * per_step + b] = cfg->timestep_map[T - 1 - k];
+    int rc = unet_prepare_embeddings(u, t_rows.data(), T * per_step, ctx, cls, B, st, shared);
     if (rc) return rc;
     LoopState *ls = unet_loop_state(u);
     if (!ls->step_ctr) {

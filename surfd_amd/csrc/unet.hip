@@ -1276,7 +1276,10 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         A.part = u->part; A.counters = u->counters;
     }
     A.cs_max = cs_max;
-    if (c.emb_off >= 0 && emb) { A.emb = emb + c.emb_off; A.emb_bstride = emb_bs; A.step_ptr = step_ptr; A.emb_step_stride = (long)B * emb_bs; }
+    if (c.emb_off >= 0 && emb) {
+        A.emb = emb + c.emb_off; A.step_ptr = step_ptr;
+        A.emb_bstride = u->emb_shared ? 0 : emb_bs; A.emb_step_stride = u->emb_shared ? emb_bs : (long)B * emb_bs;
+    }
     if (c.res.buf != -1) { const Resolved r = resolve(c.res, c.ds_out, 0, false); A.res = r.ptr; A.res_bstride = r.bstride; }
     const Resolved o = resolve(c.dst, c.ds_out, 0, true);
     A.out = o.ptr; A.out_bstride = o.bstride;
@@ -1317,8 +1320,12 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
 
 namespace surfd {
 
+// rows = one per (step, sample), or — `shared`: nothing but the timestep enters the embedding (no context, no labels) —
+// one per step, read by every sample with a batch stride of 0
 int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, const float *ctx, const int64_t *cls,
-                                int B, hipStream_t st) {
+                                int B, hipStream_t st, bool shared) {
+    if (shared && (ctx || cls)) SURFD_FAIL(SURFD_ERR_ARG, "unet: shared embedding rows need an unconditional evaluation");
+    if ((u->emb_shared != 0) != shared) { u->emb_shared = shared; u->ws_gen++; }       // captured graphs hold the strides
     if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
     if ((u->cfg.num_classes > 0) != (cls != nullptr))
         SURFD_FAIL(SURFD_ERR_ARG, "unet: class labels must be given if and only if the model is class-conditional");
@@ -1333,7 +1340,7 @@ int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, c
         u->ws_gen++;
     }
     const int mc = u->cfg.model_channels;
-    hipLaunchKernelGGL(temb_kernel, dim3(std::min(ceil_div(rows * mc / 2, 256), 1024)), dim3(256), 0, st, t_dev, rows, mc, u->temb);
+    hipLaunchKernelGGL(temb_kernel, dim3((unsigned)std::min<long>(ceil_div<long>((long)rows * mc / 2, 256), 1024)), dim3(256), 0, st, t_dev, rows, mc, u->temb);
     LAUNCH_CHECK();
     int rc;
     {
@@ -1359,7 +1366,7 @@ int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, c
         }
     }
     if (cls) {
-        hipLaunchKernelGGL(add_label_kernel, dim3(std::min(ceil_div(rows * u->ted, 256), 2048)), dim3(256), 0, st, u->emb, rows,
+        hipLaunchKernelGGL(add_label_kernel, dim3((unsigned)std::min<long>(ceil_div<long>((long)rows * u->ted, 256), 2048)), dim3(256), 0, st, u->emb, rows,
                            u->ted, (const float *)u->label_table, cls, B);
         LAUNCH_CHECK();
     }
@@ -1372,7 +1379,7 @@ int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, c
 }
 
 int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows, const float *ctx, const int64_t *cls,
-                            int B, hipStream_t st) {
+                            int B, hipStream_t st, bool shared) {
     if (rows > u->t_cap) {
         if (u->t_dev) HIP_TRY(hipFree(u->t_dev));
         u->t_dev = nullptr;
@@ -1381,7 +1388,7 @@ int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows,
     }
     HIP_TRY(hipMemcpyAsync(u->t_dev, t_rows_host, (size_t)rows * sizeof(int64_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // the host vector may go away after we return
-    return unet_prepare_embeddings_dev(u, u->t_dev, rows, ctx, cls, B, st);
+    return unet_prepare_embeddings_dev(u, u->t_dev, rows, ctx, cls, B, st, shared);
 }
 
 LoopState *unet_loop_state(surfd_unet *u) { return &u->loop; }
@@ -1412,7 +1419,7 @@ static int run_op(surfd_unet *u, const Op &op, const float *x, float *out, int B
 int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st,
                           const int *step_ptr) {
     if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
-    if (row0 < 0 || row0 + B > u->emb_rows) SURFD_FAIL(SURFD_ERR_STATE, "unet: embedding rows [%d,%d) not prepared", row0, row0 + B);
+    if (row0 < 0 || row0 + (u->emb_shared ? 1 : B) > u->emb_rows) SURFD_FAIL(SURFD_ERR_STATE, "unet: embedding rows [%d,%d) not prepared", row0, row0 + B);
     int max_ds = 1;
     for (auto &b : u->bufs) max_ds = std::max(max_ds, b.ds);
     if (L % max_ds || L < max_ds || L > 64 || (L & (L - 1))) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "unet: latent length %d must be a power of two in [%d, 64]", L, max_ds);
@@ -1511,7 +1518,7 @@ extern "C" int surfd_unet_forward(surfd_unet *u, const float *x, const int64_t *
                                   float *out, int B, int L, surfd_stream s) {
     if (!u || !x || !t || !out || B < 1 || L < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_forward: bad argument");
     hipStream_t st = as_stream(s);
-    int rc = surfd::unet_prepare_embeddings_dev(u, t, B, ctx, cls, B, st);
+    int rc = surfd::unet_prepare_embeddings_dev(u, t, B, ctx, cls, B, st, false);
     if (rc) return rc;
     return surfd::unet_forward_prepared(u, x, 0, out, B, L, st);
 }

@@ -6,11 +6,12 @@ namespace surfd {
 // Precomputes, for `rows` (step, sample) pairs, everything of the denoiser that depends only
 // on the timestep / conditioning (time_embed MLP, label/context embedding, the 22 ResBlock
 // emb_layers): t_rows[rows] are original-scale timesteps (host), row r uses sample r % B.
+// shared: nothing but t enters the embedding (no context, no labels) -> one row per step, read by every sample.
 int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows, const float *ctx,
-                            const int64_t *cls, int B, hipStream_t st);
-// One denoiser evaluation using embedding rows [row0, row0 + B) of the prepared table.  With
-// step_ptr != nullptr the row block is (*step_ptr) * B instead (read on the device: lets one
-// captured hipGraph serve every iteration of the reverse loop).
+                            const int64_t *cls, int B, hipStream_t st, bool shared = false);
+// One denoiser evaluation using embedding rows [row0, row0 + B) of the prepared table (row row0 alone when the rows
+// are shared).  With step_ptr != nullptr the row block is (*step_ptr) * B (resp. row *step_ptr) instead (read on the
+// device: lets one captured hipGraph serve every iteration of the reverse loop).
 int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st,
                           const int *step_ptr = nullptr);
 

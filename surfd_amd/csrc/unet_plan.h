@@ -70,6 +70,7 @@ struct surfd_unet {
     // workspace (grow-only)
     std::vector<float *> buf_ptr; int ws_B = 0, ws_L = 0;
     float *temb = nullptr, *h1 = nullptr, *emb = nullptr, *emb_table = nullptr; int emb_rows_cap = 0; int emb_rows = 0, emb_B = 0;
+    int emb_shared = 0;                                // 1: one embedding row per loop step, shared by all samples (no context / labels)
     int64_t *t_dev = nullptr; int t_cap = 0;
     float *part = nullptr; size_t part_floats = 0;     // split-K partial tiles
     long long *dbg = nullptr; int dbg_launch = 0;      // SURFD_CONV_DEBUG=1: per-launch phase stamps
