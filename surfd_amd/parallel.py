@@ -143,8 +143,8 @@ class BatchPipeline:
         self.decoder, self.sample_fn, self.fill_fn = decoder, sample_fn, fill_fn
         self.decoder_blocks = int(decoder_blocks)
         self.loop_chains = max(1, int(loop_chains))
-        # chain 0 runs at high priority: when all chains start together (pipeline fill) the first batch still finishes
-        # in about the time of a loop running alone, so the grids have work early
+        # chain 0 is created at high stream priority; measured (tools/pipeline_timeline.py), the hardware shares the chip
+        # about equally between the chains anyway, so the first grids start when the first ROUND of loops is done
         self.loop_streams = [torch.cuda.Stream(priority=-1 if q == 0 else 0) for q in range(self.loop_chains)]
         self.fill_stream = torch.cuda.Stream()
 
