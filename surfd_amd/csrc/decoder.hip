@@ -179,7 +179,13 @@ struct WStages { f16x8 b[4][4][2]; };        // D = 4 stages x 4 channel tiles x
 template <int KS>
 __device__ __forceinline__ void load_wstage(f16x8 (&dst)[4][2], const _Float16 *Whf, unsigned lofs, int ks) {
     // uniform base (SGPRs) + 32-bit per-lane byte offset: fragment (nt, ks, plane) at ((nt*KS + ks)*2 + plane) KiB
-    const __attribute__((address_space(1))) char *wb = (const __attribute__((address_space(1))) char *)Whf;
+    // The four channel-tile bases are re-derived from the one matrix base at every use (two scalar adds each): kept live
+    // as four SGPR pairs per matrix they were spilled in the rolled layer loop, and every reload of a spilled scalar is a
+    // scratch load + s_waitcnt vmcnt(0) — a full drain of the weight pipeline in the middle of the GEMM.
+    const unsigned long long wa = (unsigned long long)Whf;
+    unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)wa), whi = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32));
+    asm volatile("" : "+s"(wlo), "+s"(whi));
+    const __attribute__((address_space(1))) char *wb = (const __attribute__((address_space(1))) char *)(((unsigned long long)whi << 32) | wlo);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -210,13 +216,21 @@ __device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *W
         dst[0][0] = *reinterpret_cast<const f16x8 *>(a0 + ks * 8); dst[0][1] = *reinterpret_cast<const f16x8 *>(a0 + 256 + ks * 8);
         dst[1][0] = *reinterpret_cast<const f16x8 *>(a1 + ks * 8); dst[1][1] = *reinterpret_cast<const f16x8 *>(a1 + 256 + ks * 8);
     };
+    auto load_xg = [&](f16x8 (&dst)[2][2], int goff, int j) {       // k-step j of the group whose first operand column is goff
+        dst[0][0] = *reinterpret_cast<const f16x8 *>(a0 + goff + j * 8); dst[0][1] = *reinterpret_cast<const f16x8 *>(a0 + goff + 256 + j * 8);
+        dst[1][0] = *reinterpret_cast<const f16x8 *>(a1 + goff + j * 8); dst[1][1] = *reinterpret_cast<const f16x8 *>(a1 + goff + 256 + j * 8);
+    };
     auto group = [&](int ks0, auto last) {
+        // the group's LDS operand addresses are two registers (both point tiles) + immediates, re-derived here: as loop-carried
+        // induction variables there were six of them, spilled, and a reloaded address is a scratch load + vmcnt(0) in the GEMM
+        int goff = ks0 * 8;
+        asm volatile("" : "+v"(goff));
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int ks = ks0 + j;
             if (decltype(last)::value && j >= 1) load_wstage<KSN>(ws.b[(j + D - 1) % D], Wnext, lofs, j - 1);
             else load_wstage<KS>(ws.b[(j + D - 1) % D], Whf, lofs, ks + D - 1);
-            load_x(x[(j + 1) & 1], (decltype(last)::value && j == D - 1) ? ks : ks + 1);
+            load_xg(x[(j + 1) & 1], goff, (decltype(last)::value && j == D - 1) ? j : j + 1);
             mfma_step_f16x2(x[j & 1], ws.b[j], acc);
             // issue order: one memory instruction per MFMA, then the remaining MFMAs
 #pragma unroll

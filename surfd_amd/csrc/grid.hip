@@ -128,6 +128,7 @@ struct surfd_grid {
     bool dense_last = false;
     long dense_n = 0;
     int *sort_out = nullptr; void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;   // callback path: deterministic list order
+    void *sel_tmp = nullptr; size_t sel_tmp_bytes = 0;                                // fused path: ordered compaction of the gradient voxels
 };
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -152,6 +153,23 @@ static int sort_list(surfd_grid *g, int *list, long n, hipStream_t st) {
     return SURFD_OK;
 }
 
+// Gradient voxels of the fused fill = all voxels of the finished grid below the threshold, in voxel order, by one ordered
+// stream compaction (count stays on the device).  The forward kernels could collect the same SET with atomic appends,
+// but in a different order every run, and the f16x2 gradient kernel's per-tile power-of-two scaling makes the last bits
+// of a direction depend on which points share its 64-point tile: ordered list -> a fill is bitwise reproducible.
+struct BelowThreshold {
+    const float *udf; float thr;
+    __device__ __forceinline__ bool operator()(const int &i) const { return udf[i] < thr; }
+};
+
+static int compact_grad_list(surfd_grid *g, const float *udf, float thr, hipStream_t st) {
+    const int N3 = g->N * g->N * g->N;
+    hipcub::CountingInputIterator<int> idx(0);
+    size_t bytes = g->sel_tmp_bytes;
+    HIP_TRY(hipcub::DeviceSelect::If(g->sel_tmp, bytes, idx, g->grad_list, g->counters + CTR_GRAD, N3, BelowThreshold{udf, thr}, st));
+    return SURFD_OK;
+}
+
 static int grid_alloc(surfd_grid *g) {
     if (g->allocated) return SURFD_OK;
     const long N3 = (long)g->N * g->N * g->N;
@@ -164,6 +182,11 @@ static int grid_alloc(surfd_grid *g) {
     HIP_TRY(hipMalloc((void **)&g->far_list, far_cap * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->grad_list, N3 * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->sort_out, N3 * sizeof(int)));
+    {
+        hipcub::CountingInputIterator<int> idx(0);
+        HIP_TRY(hipcub::DeviceSelect::If(nullptr, g->sel_tmp_bytes, idx, g->grad_list, g->counters, (int)N3, BelowThreshold{nullptr, 0.f}, nullptr));
+        HIP_TRY(hipMalloc(&g->sel_tmp, g->sel_tmp_bytes));
+    }
     HIP_TRY(hipMalloc((void **)&g->counters, CTR_TOTAL * sizeof(int)));
     HIP_TRY(hipMemset(g->counters, 0, CTR_TOTAL * sizeof(int)));
     g->allocated = true;
@@ -239,6 +262,7 @@ void surfd_grid_destroy(surfd_grid *g) {
     if (g->counters) (void)hipFree(g->counters);
     if (g->sort_out) (void)hipFree(g->sort_out);
     if (g->sort_tmp) (void)hipFree(g->sort_tmp);
+    if (g->sel_tmp) (void)hipFree(g->sel_tmp);
     delete g;
 }
 
@@ -263,11 +287,11 @@ int surfd_grid_fill(surfd_grid *g, surfd_decoder *d, int sample, float *udf, flo
     for (int l = 0; l < g->n_levels; ++l) {
         PtIO io = eval_io(g, l);
         io.grid_udf = udf;
-        if (grads) { io.grad_list = g->grad_list; io.grad_count = g->counters + CTR_GRAD; io.grad_thr = g->grad_thr; }
         if ((rc = decoder_launch(d, sample, io, false, l == 0 ? ceil_div<long>(io.n, 64) : -1, st))) return rc;
-        if ((rc = refine_level(g, l, udf, grads != nullptr, st))) return rc;
+        if ((rc = refine_level(g, l, udf, false, st))) return rc;
     }
     if (grads) {
+        if ((rc = compact_grad_list(g, udf, g->grad_thr, st))) return rc;
         PtIO io = base_io(g);
         io.mode = PT_LIST; io.list = g->grad_list; io.count_dev = g->counters + CTR_GRAD; io.grid_grads = grads;
         if ((rc = decoder_launch(d, sample, io, true, -1, st))) return rc;
@@ -288,9 +312,9 @@ int surfd_grid_fill_dense(surfd_grid *g, surfd_decoder *d, int sample, float gra
     if (grads) HIP_TRY(hipMemsetAsync(grads, 0, N3 * 3 * sizeof(float), st));
     PtIO io = base_io(g);
     io.mode = PT_DENSE; io.n = N3; io.grid_udf = udf;
-    if (grads) { io.grad_list = g->grad_list; io.grad_count = g->counters + CTR_GRAD; io.grad_thr = grad_below; }
     if ((rc = decoder_launch(d, sample, io, false, ceil_div<long>(N3, 64), st))) return rc;
     if (grads) {
+        if ((rc = compact_grad_list(g, udf, grad_below, st))) return rc;
         PtIO gi = base_io(g);
         gi.mode = PT_LIST; gi.list = g->grad_list; gi.count_dev = g->counters + CTR_GRAD; gi.grid_grads = grads;
         if ((rc = decoder_launch(d, sample, gi, true, -1, st))) return rc;
