@@ -381,8 +381,8 @@ def main():
     kname = ("decoder_kernel<false, f16x2> (fused encode + 11-layer CBN MLP + sigmoid; split-fp16 operands, fp32 accumulate)"
              if f16 else "decoder_kernel<false> (fused encode + 11-layer CBN MLP + sigmoid)")
     dtype = ("f32 (every matrix product of decoder and denoiser as three split-fp16 products on the fp16 MFMA pipe with fp32 "
-             "accumulation — fp32-class error, same golden tolerances as the exact-fp32 kernels; gradient kernel, samplers and "
-             "grid in exact fp32)") if f16 and a.unet_precision == "f16x2" else "f32"
+             "accumulation — fp32-class error, same golden tolerances as the exact-fp32 kernels; samplers, attention, "
+             "embedding MLP and grid bookkeeping in exact fp32)") if f16 and a.unet_precision == "f16x2" else "f32"
     pmc = committed_traffic()
     # reverse loop against its roofline: per evaluation max(weight bytes / HBM, B * flops / matrix peak)
     flops_eval = B * UNET_FLOP_PER_SAMPLE.get(a.latent, 2.057e9 * a.latent / 32)
