@@ -222,10 +222,11 @@ int surfd_xattn_set_param(surfd_xattn *a, const char *name, const float *src, co
 // context_dim == query_dim); mask [B, M] bytes (non-zero = attend) or NULL; out [B, N, query_dim].  All device, fp32.
 int surfd_xattn_forward(surfd_xattn *a, const float *x, const float *context, const unsigned char *mask, float *out,
                         int B, int N, int M, surfd_stream s) {
-    if (!a || !out || (!x && (long)B * N > 0)) SURFD_FAIL(SURFD_ERR_ARG, "surfd_xattn_forward: null argument");
+    if (!a) SURFD_FAIL(SURFD_ERR_ARG, "surfd_xattn_forward: null handle");
     for (int i = 0; i < 5; ++i) if (!a->have[i]) SURFD_FAIL(SURFD_ERR_STATE, "surfd_xattn_forward: parameters not loaded");
     if (B < 0 || N < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_xattn_forward: negative size");
-    if (B == 0 || N == 0) return SURFD_OK;
+    if (B == 0 || N == 0) return SURFD_OK;                           // empty batch: nothing to do (pointers may be null)
+    if (!x || !out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_xattn_forward: null argument");
     int cdim = a->cdim;
     if (!context) {
         if (a->cdim != a->qdim) SURFD_FAIL(SURFD_ERR_ARG, "surfd_xattn_forward: self-attention needs context_dim == query_dim");
