@@ -406,7 +406,7 @@ def main():
                    "fp16_range_saturations": sat,
                    "pipeline": (f"{len(chains)} reverse loops of different batches in flight (own stream + context each) next to the "
                                 f"grids of an older batch (each loop sizes its split-K for {a.loop_cus} CUs); the decoder kernels run on {a.decoder_blocks} of the 256 CUs while loops "
-                                "are in flight and on all of them for the last batch; every batch runs start to finish inside the "
+                                "are in flight and on all of them for the last round of batches; every batch runs start to finish inside the "
                                 "timed region") if a.pipeline else "none (loop then grids, one stream)",
                    "parallelism": f"shape-parallel x{world}, no data-path collective (latents all_gathered after the timed region)"},
         "roofline": {"kernel": kname, "bound": "mfma",
@@ -417,7 +417,7 @@ def main():
                      "launches": fwd_launches, "avg_launch_ms": fwd_ms / max(fwd_launches, 1),
                      "flop_per_point": FWD_FLOP,
                      "issued_tflops": (3.0 if f16 else 1.0) * algorithmic, "issued_frac": (3.0 if f16 else 1.0) * algorithmic / peak,
-                     "cus": (f"{a.decoder_blocks} of 256 while loops are in flight, 256 for the last batch; peak is the whole chip's")
+                     "cus": (f"{a.decoder_blocks} of 256 while loops are in flight, 256 for the last round of batches; peak is the whole chip's")
                             if a.pipeline else "256"},
         "roofline_loop": {"kernel": "conv2_kernel<8,false> x84 + attn_kernel x16 per denoiser evaluation (hipGraph replay)",
                           "bound": "hbm", "achieved": streamed_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

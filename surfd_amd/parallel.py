@@ -128,8 +128,8 @@ class BatchPipeline:
     run concurrently, each on its own HIP stream and its own execution context (`MDM.replica()`: shared weights,
     private workspace / captured graph), while the grids of finished batches (matrix-pipe bound) are evaluated on
     another stream.  The decoder kernels are persistent (one workgroup per CU), so the chip is split simply by
-    their grid size (`CbnDecoder.set_grid_blocks`): while loops are in flight they take `decoder_blocks` CUs, once
-    no loop is left to overlap all of them.  Results are identical to running the batches one after the other
+    their grid size (`CbnDecoder.set_grid_blocks`): while loops of a later round are in flight they take
+    `decoder_blocks` CUs, for the last round of batches all of them.  Results are identical to running the batches one after the other
     (tests/test_gpu_unet.py).
 
         pipe = BatchPipeline(decoder, sample_fn, fill_fn, decoder_blocks=160, loop_chains=2)
@@ -188,7 +188,9 @@ class BatchPipeline:
                 assert s == f
                 with torch.cuda.stream(self.fill_stream):
                     self.fill_stream.wait_event(ev)
-                    overlapped = f + 1 < n_batches            # some loop is still running next to these grids
+                    # a loop of a LATER round is running next to these grids (the chains of one round finish together,
+                    # so the grids of the last round have the chip to themselves)
+                    overlapped = f < Q * ((n_batches - 1) // Q)
                     self.decoder.set_grid_blocks(self.decoder_blocks if overlapped else 0)
                     self.fill_fn(f, x)
         finally:
