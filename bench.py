@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--workload", choices=["real", "trace"], default="real",
                     help="real: coarse-to-fine grids of the synthetic decoder (the headline); trace: the decoder kernels over the "
                          "query lists a trained-model-like thin-shell field produces (SURVEY.md §8d W-trace)")
+    ap.add_argument("--timeline", action="store_true", help="print per-batch loop / grid completion times of the timed region to stderr")
     ap.add_argument("--no-trace", action="store_true", help="skip the untimed W-trace measurement")
     ap.add_argument("--no-e2", action="store_true", help="skip the E2 (through marching cubes) estimate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -323,12 +324,17 @@ def main():
             pipe.run(k_steps)
 
     run_steps(a.warmup)
+    pipe.record_timeline = a.timeline
     barrier(world)
     L.surfd_profile_enable(1)
     t0 = time.perf_counter()
     run_steps(a.steps)
     barrier(world)
     elapsed = time.perf_counter() - t0
+    if a.timeline and a.pipeline:
+        for m in pipe.timeline:
+            print("[timeline] batch %2d: loop done %8.1f ms, grids %8.1f -> %8.1f ms" % (m["batch"], m["loop_done_ms"], m["grids_start_ms"], m["grids_done_ms"]), file=sys.stderr)
+        pipe.record_timeline = False
     L.surfd_profile_enable(0)
     prof = {}
     for kind, name in [(0, "dec_fwd"), (1, "dec_grad"), (2, "loop")]:

@@ -147,6 +147,8 @@ class BatchPipeline:
         # about equally between the chains anyway, so the first grids start when the first ROUND of loops is done
         self.loop_streams = [torch.cuda.Stream(priority=-1 if q == 0 else 0) for q in range(self.loop_chains)]
         self.fill_stream = torch.cuda.Stream()
+        self.record_timeline = False        # True: run() leaves per-batch (loop done, grids start, grids done) times in .timeline
+        self.timeline = []
 
     def run(self, n_batches: int) -> None:
         """One host thread per loop chain (a loop call blocks its caller while the device queue is full — the 1000
@@ -161,6 +163,11 @@ class BatchPipeline:
         self.fill_stream.wait_stream(cur)
         ready = [queue.Queue() for _ in range(Q)]
         errors = []
+        marks = []
+        t_begin = None
+        if self.record_timeline:
+            t_begin = torch.cuda.Event(enable_timing=True)
+            t_begin.record(cur)
 
         def chain_worker(q):
             try:
@@ -169,7 +176,7 @@ class BatchPipeline:
                     with torch.cuda.stream(self.loop_streams[q]):
                         x = self.sample_fn(s, q)
                         x.record_stream(self.fill_stream)
-                        ev = torch.cuda.Event()
+                        ev = torch.cuda.Event(enable_timing=self.record_timeline)
                         ev.record(self.loop_streams[q])
                     ready[q].put((s, x, ev))
             except BaseException as e:          # surfaced on the calling thread
@@ -192,7 +199,12 @@ class BatchPipeline:
                     # so the grids of the last round have the chip to themselves)
                     overlapped = f < Q * ((n_batches - 1) // Q)
                     self.decoder.set_grid_blocks(self.decoder_blocks if overlapped else 0)
+                    if self.record_timeline:
+                        e0 = torch.cuda.Event(enable_timing=True); e0.record(self.fill_stream)
                     self.fill_fn(f, x)
+                    if self.record_timeline:
+                        e1 = torch.cuda.Event(enable_timing=True); e1.record(self.fill_stream)
+                        marks.append((f, ev, e0, e1))
         finally:
             for w in workers:
                 w.join()
@@ -202,3 +214,7 @@ class BatchPipeline:
             cur.wait_stream(self.fill_stream)
         if errors:
             raise errors[0]
+        if self.record_timeline:
+            torch.cuda.synchronize()
+            self.timeline = [{"batch": f, "loop_done_ms": t_begin.elapsed_time(ev), "grids_start_ms": t_begin.elapsed_time(e0),
+                              "grids_done_ms": t_begin.elapsed_time(e1)} for f, ev, e0, e1 in marks]
