@@ -72,3 +72,22 @@ def test_roofline_constants(bench):
 def test_cpu_model_is_reported(bench):
     m = bench.cpu_model()
     assert isinstance(m, str) and len(m) > 0
+
+
+def test_committed_traffic_is_what_the_tool_derives(tmp_path, bench):
+    """roofline.traffic comes from profiles/r02_pmc_traffic.json; that file must be exactly what tools/pmc_to_traffic.py
+    derives from the committed PMC summary (KiB units, FETCH_SIZE doubled on gfx950), not a hand-edited number."""
+    import json
+    import subprocess
+    src = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    out = tmp_path / "traffic.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_to_traffic.py"), src, str(out)],
+                          stdout=subprocess.DEVNULL, cwd=ROOT)
+    derived = json.load(open(out))
+    committed = bench.committed_traffic()
+    for k, v in derived.items():
+        if isinstance(v, float):
+            assert committed[k] == pytest.approx(v, rel=1e-12), k
+    summary = json.load(open(src))
+    dec = [v for k, v in summary["fetch"].items() if "decoder_kernel<false, true>" in k][0]
+    assert committed["decoder_fwd_fetch_bytes_per_launch"] == pytest.approx(dec["FETCH_SIZE"] * 1024 * 2 / dec["dispatches"])
