@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--workload", choices=["real", "trace"], default="real",
                     help="real: coarse-to-fine grids of the synthetic decoder (the headline); trace: the decoder kernels over the "
                          "query lists a trained-model-like thin-shell field produces (SURVEY.md §8d W-trace)")
+    ap.add_argument("--batch-grids", type=int, default=1,
+                    help="1: the grids of a batch are refined together, one decoder launch per level for all shapes "
+                         "(meshudf.fill_grids); 0: shape after shape")
     ap.add_argument("--timeline", action="store_true", help="print per-batch loop / grid completion times of the timed region to stderr")
     ap.add_argument("--no-trace", action="store_true", help="skip the untimed W-trace measurement")
     ap.add_argument("--no-e2", action="store_true", help="skip the E2 (through marching cubes) estimate")
@@ -268,6 +271,7 @@ def main():
     from surfd_amd import synth
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
+    from surfd_amd.meshudf import fill_grids as fill_grids_batch
     L = Nn.lib()
     model, diffusion, dec = build_models(a.latent, a.decoder_precision, a.unet_precision)
     if a.diffusion_steps != 1000:
@@ -278,6 +282,7 @@ def main():
     first = rank * B                                     # global index of this rank's first shape
     noise = synth.synth_noise_batch(T, first, B, a.latent).cuda()
     filler = GridFiller(N)
+    fillers = [filler] + [GridFiller(N) for _ in range(B - 1)] if a.batch_grids and B <= 8 else None
     udf = [torch.empty(N, N, N, device="cuda") for _ in range(B)]
     grads = [torch.empty(N, N, N, 3, device="cuda") for _ in range(B)]
     stats = []
@@ -296,6 +301,10 @@ def main():
 
     def fill_grids(lat, collect=False):
         dec.bind_latents(lat.reshape(B, a.latent))
+        if fillers is not None and trace is None and not collect:
+            # all shapes of the batch level by level together: one persistent decoder launch per level (meshudf.fill_grids)
+            fill_grids_batch(fillers, dec, list(range(B)), [(udf[k], grads[k]) for k in range(B)])
+            return
         for k in range(B):
             if trace is not None:                        # W-trace: the decoder kernels over the trained-model-like query lists
                 for kind, c in trace:

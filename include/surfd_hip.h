@@ -217,6 +217,12 @@ int surfd_grid_set_thresholds(surfd_grid *g, const float *refine, int n_levels, 
  * utils/utils.py:151-339). */
 int surfd_grid_fill(surfd_grid *g, surfd_decoder *d, int sample, float *udf, float *grads,
                     surfd_stream s);
+/* The same for the grids of n <= 8 shapes at once (what the sample scripts do shape after shape, generate_uncond.py:
+ * 91-123): one grid handle, bound-latent index, udf and grads (entries or the array may be NULL) pointer per shape.
+ * Every refinement level of all shapes is ONE launch of the persistent decoder kernel; values are bit-identical to n
+ * calls of surfd_grid_fill.  No reference counterpart (throughput form). */
+int surfd_grid_fill_batch(surfd_grid *const *grids, int n, surfd_decoder *d, const int *samples, float *const *udf,
+                          float *const *grads, surfd_stream s);
 /* get_udf_and_grads (use_fast_grid_filler=False): all N^3 points, gradients where
  * udf < grad_below (= max_dist - 1e-3 in the reference). */
 int surfd_grid_fill_dense(surfd_grid *g, surfd_decoder *d, int sample, float grad_below,

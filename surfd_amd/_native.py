@@ -77,6 +77,7 @@ _SIGS = {
     "surfd_grid_destroy": (None, [_P]),
     "surfd_grid_set_thresholds": (C.c_int, [_P, c_f32p, C.c_int, C.c_float, C.c_float, C.c_float]),
     "surfd_grid_fill": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "surfd_grid_fill_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "surfd_grid_fill_dense": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P]),
     "surfd_grid_get_stats": (C.c_int, [_P, C.POINTER(GridStats), _P]),
     "surfd_grid_begin": (C.c_int, [_P, _P, _P, _P]),

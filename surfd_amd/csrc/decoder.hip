@@ -86,7 +86,7 @@ struct DecParams {
     const float *wpack;   // WPACK_FLOATS
     const _Float16 *whf;  // WHF_ELEMS (f16x2 kernels only)
     const float *vecs;    // VEC_FLOATS: biases, w_out, b_out
-    const float *tab;     // this sample's [NCBN][2][H] scale/shift
+    const float *tab;     // [S][NCBN][2][H] scale/shift tables of the bound latents
     int input_dim;
     unsigned *sat;        // f16x2 forward path: waves that saw an activation beyond the fp16 range (it is clamped)
 };
@@ -292,7 +292,7 @@ __device__ long long g_dec_stamps[8];
 #endif
 
 template <bool GRAD, bool F16X2 = false>
-__global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
+__global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *X = lds;                      // [TP][XS]
     float *E = lds;                      // [TP][ES] first-layer input, aliases X (dead before X is written)
@@ -305,8 +305,6 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: keeps weight bases in SGPRs
-    const long npts = pt_count(io);
-    const long ntiles = (npts + TP - 1) / TP;
     // per-lane LDS bases of this wave's accumulator footprint in X (one per point tile): every
     // element (mt, nt, r) is then base + compile-time offset (< 64 KB, fits the ds immediate)
     float *const xb0 = X + (4 * (lane >> 5)) * XS + 128 * wave + col;
@@ -388,11 +386,16 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
     if constexpr (F16X2) gemm_prefetch_f16x2<KS_E>(ws, P.whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, lane);
 
     TDECL(); int tphase_ = 0; (void)tphase_;
+    for (int bi = 0; bi < B.n; ++bi) {
+    const PtIO &io = B.io[bi];                       // kernel-argument segment: uniform loads
+    const long npts = pt_count(io);
+    const long ntiles = (npts + TP - 1) / TP;
+    const float *tab_sample = P.tab + (size_t)B.sample[bi] * NCBN * 2 * H;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long e0 = tile * TP;
         // re-materialise the arena bases per tile: keeps the compiler from hoisting ~100 derived
         // 64-bit layer addresses out of the tile loop and spilling them to scratch
-        const float *wpack_ = P.wpack, *vecs_ = P.vecs, *tab_ = P.tab;
+        const float *wpack_ = P.wpack, *vecs_ = P.vecs, *tab_ = tab_sample;
         const _Float16 *whf = P.whf;
         int cb = 128 * wave + col;          // first of this lane's four channels (+32 per tile)
         asm volatile("" : "+s"(wpack_), "+s"(vecs_), "+s"(tab_));
@@ -873,6 +876,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtIO io) {
             }
         }
     }
+    }
     if constexpr (F16X2) {
         if (sat_flag && lane == 0) atomicAdd(P.sat, 1u);
     }
@@ -1238,15 +1242,27 @@ namespace surfd {
 
 // Enqueue the decoder over a point source; used by the C entry points below and by grid.hip.
 int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles_hint, hipStream_t st) {
+    PtBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = 1; b.sample[0] = sample; b.io[0] = io;
+    return decoder_launch_batch(d, b, grad, ntiles_hint, st);
+}
+
+int decoder_launch_batch(surfd_decoder *d, const PtBatch &batch, bool grad, long ntiles_hint, hipStream_t st) {
     if (!d) SURFD_FAIL(SURFD_ERR_ARG, "decoder: null handle");
     if (!d->finalized) SURFD_FAIL(SURFD_ERR_STATE, "decoder: parameters not finalized");
-    if (sample < 0 || sample >= d->S) SURFD_FAIL(SURFD_ERR_STATE, "decoder: sample %d not bound (%d latents bound)", sample, d->S);
+    if (batch.n < 1 || batch.n > PT_BATCH_MAX) SURFD_FAIL(SURFD_ERR_ARG, "decoder: 1..%d point sources per launch", PT_BATCH_MAX);
+    PtBatch io = batch;
+    for (int i = 0; i < io.n; ++i) {
+        if (io.sample[i] < 0 || io.sample[i] >= d->S)
+            SURFD_FAIL(SURFD_ERR_STATE, "decoder: sample %d not bound (%d latents bound)", io.sample[i], d->S);
+        io.io[i].emb_dim = d->input_dim;
+    }
     DecParams P;
     P.wpack = d->wpack; P.vecs = d->vecs; P.whf = d->whf;
-    P.tab = d->tab + (size_t)sample * NCBN * 2 * H;
+    P.tab = d->tab;
     P.input_dim = d->input_dim;
     P.sat = d->sat;
-    io.emb_dim = d->input_dim;
     // one workgroup per CU (LDS-limited); a device-side count is handled by the tile loop
     long blocks = d->grid_blocks > 0 ? std::min(d->grid_blocks, d->num_cus) : d->num_cus;
     if (ntiles_hint >= 0) blocks = std::min<long>(blocks, std::max<long>(ntiles_hint, 1));

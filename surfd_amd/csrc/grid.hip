@@ -300,6 +300,55 @@ int surfd_grid_fill(surfd_grid *g, surfd_decoder *d, int sample, float *udf, flo
     return SURFD_OK;
 }
 
+// The grids of `n` shapes (one handle each, all of one resolution) level by level TOGETHER: the decoder evaluates a level
+// of all shapes in one persistent launch (points.h: PtBatch), the bookkeeping kernels run per shape in between.  Same
+// values as n calls of surfd_grid_fill, bit for bit (tiles never mix shapes).
+int surfd_grid_fill_batch(surfd_grid *const *gs, int n, surfd_decoder *d, const int *samples, float *const *udfs,
+                          float *const *grads, surfd_stream s) {
+    if (!gs || !samples || !udfs || n < 1 || n > PT_BATCH_MAX)
+        SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_fill_batch: need 1..%d grids", PT_BATCH_MAX);
+    hipStream_t st = as_stream(s);
+    int rc;
+    for (int i = 0; i < n; ++i) {
+        if ((rc = check_ready(gs[i], "surfd_grid_fill_batch"))) return rc;
+        if (!udfs[i]) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_fill_batch: udf %d is null", i);
+        if (gs[i]->N != gs[0]->N || gs[i]->n_levels != gs[0]->n_levels)
+            SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_fill_batch: all grids must have one resolution");
+        for (int j = 0; j < i; ++j)
+            if (gs[j] == gs[i]) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_fill_batch: every shape needs its own grid handle");
+        if ((rc = grid_alloc(gs[i]))) return rc;
+        const long N3 = (long)gs[i]->N * gs[i]->N * gs[i]->N;
+        HIP_TRY(hipMemsetAsync(gs[i]->counters, 0, CTR_TOTAL * sizeof(int), st));
+        if (grads && grads[i]) HIP_TRY(hipMemsetAsync(grads[i], 0, N3 * 3 * sizeof(float), st));
+    }
+    for (int l = 0; l < gs[0]->n_levels; ++l) {
+        PtBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n;
+        for (int i = 0; i < n; ++i) {
+            b.sample[i] = samples[i];
+            b.io[i] = eval_io(gs[i], l);
+            b.io[i].grid_udf = udfs[i];
+        }
+        if ((rc = decoder_launch_batch(d, b, false, l == 0 ? ceil_div<long>(b.io[0].n, 64) : -1, st))) return rc;
+        for (int i = 0; i < n; ++i)
+            if ((rc = refine_level(gs[i], l, udfs[i], false, st))) return rc;
+    }
+    PtBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    for (int i = 0; i < n; ++i) {
+        gs[i]->dense_last = false;
+        if (!grads || !grads[i]) continue;
+        if ((rc = compact_grad_list(gs[i], udfs[i], gs[i]->grad_thr, st))) return rc;
+        PtIO io = base_io(gs[i]);
+        io.mode = PT_LIST; io.list = gs[i]->grad_list; io.count_dev = gs[i]->counters + CTR_GRAD; io.grid_grads = grads[i];
+        gb.sample[gb.n] = samples[i];
+        gb.io[gb.n++] = io;
+    }
+    if (gb.n && (rc = decoder_launch_batch(d, gb, true, -1, st))) return rc;
+    return SURFD_OK;
+}
+
 int surfd_grid_fill_dense(surfd_grid *g, surfd_decoder *d, int sample, float grad_below, float *udf, float *grads,
                           surfd_stream s) {
     int rc = check_ready(g, "surfd_grid_fill_dense");

@@ -88,7 +88,20 @@ __device__ __forceinline__ int wave_append_slot(int *counter, bool pred) {
     return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
 }
 
-// Enqueue the fused decoder over a point source (defined in decoder.hip).
+// Several point sources served by ONE launch of the persistent decoder kernel: every workgroup walks its tiles of source 0,
+// then of source 1, ... (each with the conditional-BN tables of its own latent `sample[i]`).  The grids of a batch of
+// shapes are at the same refinement level at the same time, so a level of all of them is one launch: no launch boundary
+// (workgroups that run out of tiles of one shape start on the next shape at once) and an eighth of the launches whose
+// persistent workgroups have to find free CUs next to the reverse loops.
+constexpr int PT_BATCH_MAX = 8;
+struct PtBatch {
+    int n;
+    int sample[PT_BATCH_MAX];
+    PtIO io[PT_BATCH_MAX];
+};
+
+// Enqueue the fused decoder over a point source / a batch of them (defined in decoder.hip).
 int decoder_launch(surfd_decoder *d, int sample, PtIO io, bool grad, long ntiles_hint, hipStream_t st);
+int decoder_launch_batch(surfd_decoder *d, const PtBatch &b, bool grad, long ntiles_hint, hipStream_t st);
 
 }  // namespace surfd

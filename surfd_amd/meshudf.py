@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Callable, Dict, Optional, Tuple
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -161,6 +161,24 @@ class GridFiller:
                 N.lib().surfd_grid_destroy(self._handle)
         except Exception:
             pass
+
+
+def fill_grids(fillers: Sequence["GridFiller"], decoder, samples: Sequence[int], outs: Sequence[Tuple[Tensor, Optional[Tensor]]]) -> None:
+    """Coarse-to-fine grids of up to 8 shapes TOGETHER (throughput form of calling GridFiller.fill_grid shape after
+    shape, as sample/generate_*.py do): `samples[i]` is the index of shape i's latent among the ones bound with
+    ``decoder.bind_latents``, `fillers[i]` its own GridFiller, `outs[i]` = (udf [N,N,N], grads [N,N,N,3] | None).  Every
+    refinement level of all shapes is one launch of the persistent decoder kernel; the values are bit-identical to the
+    per-shape calls."""
+    n = len(fillers)
+    if not (1 <= n <= 8) or len(samples) != n or len(outs) != n:
+        raise ValueError("fill_grids: 1..8 shapes, one filler / sample index / output pair each")
+    L = N.lib()
+    _, dh = decoder._native()
+    hs = (C.c_void_p * n)(*[f._native()[1] for f in fillers])
+    ss = (C.c_int * n)(*[int(s) for s in samples])
+    us = (C.c_void_p * n)(*[o[0].data_ptr() for o in outs])
+    gs = (C.c_void_p * n)(*[(o[1].data_ptr() if o[1] is not None else None) for o in outs])
+    N.check(L.surfd_grid_fill_batch(hs, n, dh, ss, us, gs, N.stream()))
 
 
 def get_udf_and_grads(udf_func, coords_range: Tuple[float, float], max_dist: float, N: int, max_batch: int):

@@ -532,3 +532,29 @@ def test_mesh_512_thin_shell_end_to_end(golden):
         assert hashlib.sha256(np.ascontiguousarray(f, np.int32).tobytes()).hexdigest() == str(g["thin_shell_512_faces_sha256"])
     del udf, grads
     torch.cuda.empty_cache()
+
+
+def test_batched_grid_fill_matches_per_shape_fill():
+    """meshudf.fill_grids (one persistent decoder launch per level for ALL shapes of a batch) against GridFiller.fill_grid
+    shape after shape: same bits, values and gradients, incl. a shape without gradients and both precisions."""
+    from surfd_amd.cbndec import make_udf_func
+    from surfd_amd.meshudf import GridFiller, fill_grids
+    dec, sd = _decoder(32)
+    S = 5
+    lat = (torch.randn(S, 32, generator=torch.Generator().manual_seed(31)) * 0.8).cuda()
+    for precision in ("f16x2", "fp32"):
+        dec.set_precision(precision)
+        dec.bind_latents(lat)
+        ref = [GridFiller(128).fill_grid(make_udf_func(dec, lat[k], sample=k), 2 ** 16, with_grads=(k != 2)) for k in range(S)]
+        ref = [(u.clone(), None if g is None else g.clone()) for u, g in ref]
+        fillers = [GridFiller(128) for _ in range(S)]
+        outs = [(torch.empty(128, 128, 128, device="cuda"), None if k == 2 else torch.empty(128, 128, 128, 3, device="cuda")) for k in range(S)]
+        fill_grids(fillers, dec, list(range(S)), outs)
+        for k in range(S):
+            assert torch.equal(outs[k][0], ref[k][0]), (precision, k)
+            if ref[k][1] is not None:
+                assert torch.equal(outs[k][1], ref[k][1]), (precision, k)
+            assert fillers[k]._stats()["fwd_per_level"][0] == 32 ** 3
+    dec.set_precision("f16x2")
+    with pytest.raises(RuntimeError):
+        fill_grids([fillers[0], fillers[0]], dec, [0, 1], outs[:2])          # one handle per shape
