@@ -301,9 +301,11 @@ def main():
 
     def fill_grids(lat, collect=False):
         dec.bind_latents(lat.reshape(B, a.latent))
-        if fillers is not None and trace is None and not collect:
+        if fillers is not None and trace is None:
             # all shapes of the batch level by level together: one persistent decoder launch per level (meshudf.fill_grids)
             fill_grids_batch(fillers, dec, list(range(B)), [(udf[k], grads[k]) for k in range(B)])
+            if collect:
+                stats.extend(f._stats() for f in fillers)
             return
         for k in range(B):
             if trace is not None:                        # W-trace: the decoder kernels over the trained-model-like query lists
