@@ -457,13 +457,13 @@ def main():
                            f"{per_shape_ms * B:.0f} ms, so the step is bound by the reverse loops ({loop_alone_ms:.0f} ms alone)")
         out["w_trace"] = w_trace
     if not a.no_e2:
-        out["e2"] = e2_estimate(a, elapsed, shapes)
-    if not a.no_cpu_baseline:
+        out["e2"] = e2_estimate(a, elapsed, shapes, world)
+    if not a.no_cpu_baseline and world == 1:          # a stated baseline of the N=1 line only
         out["cpu_baseline"] = cpu_baseline(T, B, n_fwd, n_grad)
     print(json.dumps(out))
 
 
-def e2_estimate(a, elapsed, shapes):
+def e2_estimate(a, elapsed, shapes, world=1):
     """End point E2 = E1 + marching cubes on the host.  The native mesher is timed on one analytic
     thin-shell field of the benchmark's resolution and folded in as a host-side stage that runs on other cores
     while the GPU works on the next batches."""
@@ -471,7 +471,8 @@ def e2_estimate(a, elapsed, shapes):
         from surfd_amd import mcubes
     except Exception as e:       # the mesher is a later §8f row
         return {"status": f"native marching cubes unavailable ({type(e).__name__})"}
-    return mcubes.bench_e2(a.resolution, shapes / elapsed)
+    # one meshing thread per shape of a batch and per GPU (the host of an 8-GPU node has the cores: 8 x 8 of 256)
+    return mcubes.bench_e2(a.resolution, shapes / elapsed, threads=8 * world)
 
 
 if __name__ == "__main__":
