@@ -519,7 +519,20 @@ int surfd_mc::run() {
     // scan positions 0, s, 2s, ... up to and including the first one >= bound (the reference's while-loops, pyx:1196-1206)
     for (int zi = 0;; zi += s) {
       for (int yi = 0;; yi += s) {
+        const float *row = im + vox(zi, yi, 0);
         for (int xi = 0;; xi += s) {
+            // the cube's own corner bounds its maximum from below: one sequential read rules out almost every cube of the
+            // volume without touching the other seven corners (exactly the cubes near_surface() would reject anyway)
+            if (s == 1) {
+                // (blocks of 32 corners without a candidate are skipped with a branch-free reduction the compiler vectorises)
+                while (xi + 32 <= xb) {
+                    int hit = 0;
+                    for (int k = 0; k < 32; ++k) hit |= !(row[xi + k] > max_thr);
+                    if (hit) break;
+                    xi += 32;
+                }
+            }
+            if (row[xi] > max_thr) { if (xi >= xb) break; continue; }
             if (process(zi, yi, xi, false)) {
                 probing = false;
                 while (!queue.empty() || !unsure.empty() || !hard.empty()) {
