@@ -143,8 +143,9 @@ class BatchPipeline:
         self.decoder, self.sample_fn, self.fill_fn = decoder, sample_fn, fill_fn
         self.decoder_blocks = int(decoder_blocks)
         self.loop_chains = max(1, int(loop_chains))
-        # chain 0 is created at high stream priority; measured (tools/pipeline_timeline.py), the hardware shares the chip
-        # about equally between the chains anyway, so the first grids start when the first ROUND of loops is done
+        # chain 0 is created at high stream priority.  Measured: without any high-priority chain the pipeline loses 15 %
+        # (3.94 against 4.63 shapes/s: the loops then yield to the decoder's launches); all chains high = chain 0 high.
+        # It does not make the first batch of the first round finish early (profiles/r02_pipeline_timeline.txt).
         self.loop_streams = [torch.cuda.Stream(priority=-1 if q == 0 else 0) for q in range(self.loop_chains)]
         self.fill_stream = torch.cuda.Stream()
         self.record_timeline = False        # True: run() leaves per-batch (loop done, grids start, grids done) times in .timeline
