@@ -259,6 +259,9 @@ int64_t surfd_mc_num_faces(const surfd_mc *m);
  * values[V]; any pointer may be NULL */
 int surfd_mc_copy(const surfd_mc *m, float *vertices, int32_t *faces, float *normals, float *values);
 void surfd_mc_destroy(surfd_mc *m);
+/* Wavefront OBJ writer for the meshes above ("v x y z" with 6 decimals, 1-based "f a b c"): the export step of the sample
+ * scripts (sample/generate_uncond.py:113-122).  vertices[nv,3] float64, faces[nf,3] int64, host arrays. */
+int surfd_write_obj(const char *path, const double *vertices, int64_t nv, const int64_t *faces, int64_t nf);
 /* the case tables the library was built with (Lewiner et al. 2003), for tests */
 int surfd_mc_lut_count(void);
 int surfd_mc_lut(int i, const char **name, const signed char **values, int *ndim, int dims[3]);

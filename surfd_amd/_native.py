@@ -91,6 +91,7 @@ _SIGS = {
     "surfd_mc_num_faces": (C.c_int64, [_P]),
     "surfd_mc_copy": (C.c_int, [_P, _P, _P, _P, _P]),
     "surfd_mc_destroy": (None, [_P]),
+    "surfd_write_obj": (C.c_int, [C.c_char_p, _P, C.c_int64, _P, C.c_int64]),
     "surfd_xattn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "surfd_xattn_destroy": (None, [_P]),
     "surfd_xattn_set_param": (C.c_int, [_P, C.c_char_p, _P, c_i64p, C.c_int, _P]),

@@ -663,4 +663,22 @@ int surfd_mc_lut(int i, const char **name, const signed char **values, int *ndim
     return SURFD_OK;
 }
 
+// Wavefront OBJ of a triangle mesh: "v x y z" (6 decimals) and 1-based "f a b c" lines — the text the sample scripts'
+// exports end in (sample/generate_uncond.py:113-122 via trimesh / open3d).  Host only; 2/3 of a million lines per 512^3
+// shape are too many for a Python loop.
+int surfd_write_obj(const char *path, const double *vertices, int64_t nv, const int64_t *faces, int64_t nf) {
+    if (!path || (nv > 0 && !vertices) || (nf > 0 && !faces) || nv < 0 || nf < 0) { surfd::set_error("surfd_write_obj: bad argument"); return SURFD_ERR_ARG; }
+    FILE *fh = fopen(path, "w");
+    if (!fh) { surfd::set_error("surfd_write_obj: cannot open '%s'", path); return SURFD_ERR_ARG; }
+    std::vector<char> buf(1 << 20);
+    setvbuf(fh, buf.data(), _IOFBF, buf.size());
+    fputs("# surfd_amd mesh\n", fh);
+    for (int64_t i = 0; i < nv; ++i) fprintf(fh, "v %.6f %.6f %.6f\n", vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]);
+    for (int64_t i = 0; i < nf; ++i)
+        fprintf(fh, "f %lld %lld %lld\n", (long long)faces[3 * i] + 1, (long long)faces[3 * i + 1] + 1, (long long)faces[3 * i + 2] + 1);
+    const bool bad = ferror(fh) != 0;
+    if (fclose(fh) != 0 || bad) { surfd::set_error("surfd_write_obj: write to '%s' failed", path); return SURFD_ERR_ARG; }
+    return SURFD_OK;
+}
+
 }  // extern "C"

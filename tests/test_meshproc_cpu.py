@@ -131,3 +131,18 @@ def test_clean_until_stable_pipeline():
     F = np.array([[0, 2, 1], [0, 4, 3], [1, 2, 3], [2, 1, 0], [1, 4, 2]])       # [0,3,2] missing; [1,4,2] collapses
     v, f = mp.clean_until_stable(V, F)
     assert len(v) == 4 and len(f) == 4 and (_edge_use(f) == 2).all()
+
+
+def test_native_obj_writer_text(tmp_path):
+    """meshproc.write_obj goes through the library's writer (surfd_write_obj); its text is the per-line formatting the
+    module documents ('v' lines with 6 decimals, 1-based 'f' lines), incl. rounding ties and an empty mesh."""
+    rng = np.random.default_rng(1)
+    v = rng.normal(size=(500, 3)) * np.array([1.0, 1e-3, 1e3])
+    v[0] = [0.0000005, -0.0000005, 1.0000005]
+    f = rng.integers(0, 500, size=(900, 3))
+    p = tmp_path / "a" / "m.obj"                         # the directory is created
+    mp.write_obj(str(p), v, f)
+    want = "# surfd_amd mesh\n" + "".join(f"v {x:.6f} {y:.6f} {z:.6f}\n" for x, y, z in v) + "".join(f"f {a} {b} {c}\n" for a, b, c in f + 1)
+    assert p.read_text() == want
+    mp.write_obj(str(p), np.zeros((0, 3)), np.zeros((0, 3), np.int64))
+    assert p.read_text() == "# surfd_amd mesh\n"
