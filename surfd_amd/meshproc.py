@@ -232,12 +232,16 @@ def clean_until_stable(vertices: np.ndarray, faces: np.ndarray, max_iter: int = 
     v, f = cull_and_merge(v, f)                     # Trimesh(mesh.vertices, mesh.faces) re-processes on construction
     counts, rounds = (0, 0), 0
     while counts != (len(v), len(f)) and rounds < max_iter:
-        v, f = cull_and_merge(v, f)
+        # the reference re-processes the mesh at the top of every round and again at its end; culling is idempotent and
+        # (v, f) always comes out of a cull here, so the first one is skipped, and so is the second one when the round
+        # removed no face (every vertex is then still referenced and unique: the cull would return its input)
+        n_before = len(f)
         f = drop_duplicate_faces(f)
         f = drop_degenerate_faces(v, f)
         counts = (len(v), len(f))
         rounds += 1
-        v, f = cull_and_merge(v, f)
+        if len(f) != n_before:
+            v, f = cull_and_merge(v, f)
     return v, f
 
 

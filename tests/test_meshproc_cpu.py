@@ -146,3 +146,41 @@ def test_native_obj_writer_text(tmp_path):
     assert p.read_text() == want
     mp.write_obj(str(p), np.zeros((0, 3)), np.zeros((0, 3), np.int64))
     assert p.read_text() == "# surfd_amd mesh\n"
+
+
+def _clean_spec(vertices, faces, max_iter=10):
+    """The cleaning sequence written out call by call as the reference performs it (meshudf.py:380-404), without the
+    shortcuts of meshproc.clean_until_stable."""
+    v, f = mp.cull_and_merge(vertices, faces)
+    f = mp.drop_duplicate_faces(f)
+    f = mp.drop_degenerate_faces(v, f)
+    f = mp.fill_small_holes(v, f)
+    v, f = mp.cull_and_merge(v, f)
+    counts, rounds = (0, 0), 0
+    while counts != (len(v), len(f)) and rounds < max_iter:
+        v, f = mp.cull_and_merge(v, f)
+        f = mp.drop_duplicate_faces(f)
+        f = mp.drop_degenerate_faces(v, f)
+        counts = (len(v), len(f))
+        rounds += 1
+        v, f = mp.cull_and_merge(v, f)
+    return v, f
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_clean_until_stable_equals_the_unabridged_sequence(seed):
+    """Skipping the provably idempotent re-processing steps must not change a single vertex or face — on messy meshes:
+    duplicated and unreferenced vertices, duplicate / degenerate / sliver faces, holes, non-finite coordinates."""
+    rng = np.random.default_rng(seed)
+    n = 60
+    v = rng.normal(size=(n, 3))
+    v[rng.integers(0, n, 8)] = v[rng.integers(0, n, 8)]                  # coincident vertices
+    v[5] = v[6] + 1e-10                                                  # merge within tolerance
+    if seed % 2:
+        v[7] = [np.nan, 0.0, 0.0]
+    f = rng.integers(0, n, size=(150, 3))
+    f = np.vstack([f, f[:10][:, ::-1], f[10:15], np.stack([f[:5, 0], f[:5, 0], f[:5, 1]], 1)])   # flipped / repeated / degenerate
+    a, b = mp.clean_until_stable(v, f)
+    c, d = _clean_spec(v, f)
+    assert np.array_equal(a, c) and np.array_equal(b, d)
+    assert np.array_equal(*[x[0] for x in (mp.clean_until_stable(a, b), (a, b))])            # stable: cleaning again changes nothing
