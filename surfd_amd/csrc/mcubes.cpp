@@ -15,7 +15,8 @@
 //
 // What is different: the reference allocates 4 ints per voxel for the edge->vertex cache (2.1 GB at 512^3, filled
 // with -1 up front); here the cache is paged and pages appear on first touch (the surface band is ~1 % of the grid),
-// and the sign / state volumes are calloc'ed (zero pages are only materialised where the band touches them).
+// and the per-voxel state volume (one byte: sign, final, finished) is calloc'ed (zero pages are only materialised where
+// the band touches them).
 // One shape per call, single-threaded like the reference: the host runs one call per core (bench.py, E2).
 #include "../../include/surfd_hip.h"
 #include "mc_luts.h"
@@ -118,9 +119,15 @@ static inline float dot3(const float *a, const float *b) { return a[0] * b[0] + 
 struct surfd_mc {
     int nx = 0, ny = 0, nz = 0, st = 1;
     const float *im = nullptr, *gr = nullptr;
-    float *sign = nullptr;              // per-voxel sign (+1 / -1 / 0 = not set)
-    unsigned char *fixed = nullptr;     // sign is final (the voxel was a corner of a processed cube)
-    unsigned char *seen = nullptr;      // cube (by its low corner) is finished
+    // one byte of state per voxel — bits 0-1: sign of the voxel (0 = not set, 1 = +1, 2 = -1), bit 2: the sign is final (the
+    // voxel was a corner of a processed cube), bit 3: the cube whose low corner this is has been finished.  One packed
+    // array instead of a float and two byte volumes: the band touches a sixth of the pages (every first touch of a page
+    // of the calloc'ed volume is a page fault; they were a third of the run time at 512^3)
+    unsigned char *state = nullptr;
+    float sign_of(size_t p) const { static const float t[4] = {0.f, 1.f, -1.f, 0.f}; return t[state[p] & 3]; }
+    void set_sign(size_t p, float s) { state[p] = (unsigned char)((state[p] & ~3u) | (s > 0.f ? 1u : (s < 0.f ? 2u : 0u))); }
+    bool is_fixed(size_t p) const { return state[p] & 4; }
+    bool is_seen(size_t p) const { return state[p] & 8; }
     std::unique_ptr<EdgeCache> cache;
     // current cube
     int cx = 0, cy = 0, cz = 0, pattern = 0;
@@ -133,7 +140,7 @@ struct surfd_mc {
     std::vector<float> verts, normals, values;
     std::vector<int> faces;
 
-    ~surfd_mc() { free(sign); free(fixed); free(seen); }
+    ~surfd_mc() { free(state); }
 
     size_t vox(int z, int y, int x) const { return ((size_t)z * ny + y) * nx + x; }
 
@@ -433,7 +440,7 @@ int surfd_mc::run() {
     // Returns true when the cube produced triangles (a seed then starts the growth).
     bool probing = false;             // growth only: the neighbours of an unsure cube are being pre-voted
     auto process = [&](int z, int y, int x, bool grow) -> bool {
-        if (seen[vox(z, y, x)] || !near_surface(z, y, x)) return false;
+        if (is_seen(vox(z, y, x)) || !near_surface(z, y, x)) return false;
         const int cz_[8] = {z, z, z, z, z + s, z + s, z + s, z + s};
         const int cy_[8] = {y, y, y + s, y + s, y, y, y + s, y + s};
         const int cx_[8] = {x, x + s, x + s, x, x, x + s, x + s, x};
@@ -442,7 +449,7 @@ int surfd_mc::run() {
         for (int k = 0; k < 8; ++k) {
             votes[k] = 0; tally[k] = 0.f;
             const size_t p = vox(cz_[k], cy_[k], cx_[k]);
-            if (fixed[p]) { votes[k] = 1; tally[k] = sign[p]; continue; }
+            if (is_fixed(p)) { votes[k] = 1; tally[k] = sign_of(p); continue; }
             if (im[p] == 0.0f) { votes[k] = 1; continue; }
             for (int d = 0; d < 6; ++d) {
                 int i = 0, reach = 1;
@@ -452,16 +459,17 @@ int surfd_mc::run() {
                     if (qz > zb || qz < 0 || qy > yb || qy < 0 || qx > xb || qx < 0) break;
                     const size_t q = vox(qz, qy, qx);
                     if (im[q] == 0.0f) { if (i >= reach) ++reach; continue; }      // look past exact zeros
-                    if (sign[q] == 0.0f) continue;
+                    const float sq = sign_of(q);
+                    if (sq == 0.0f) continue;
                     ++votes[k];
-                    tally[k] += sign[q] * edge_vote(gr + 3 * p, gr + 3 * q, dirs[d][0], dirs[d][1], dirs[d][2]);
+                    tally[k] += sq * edge_vote(gr + 3 * p, gr + 3 * q, dirs[d][0], dirs[d][1], dirs[d][2]);
                 }
             }
             if (grow && votes[k] >= 1 && (double)fabsf(tally[k]) / (double)votes[k] < unsure_thr && !queue.empty()) {
                 if (!probing) unsure.push_back({z, y, x});
                 return false;
             }
-            sign[p] = sgn(tally[k]);           // provisional: usable by later votes, recomputed until the cube is processed
+            set_sign(p, sgn(tally[k]));        // provisional: usable by later votes, recomputed until the cube is processed
         }
         bool all_voted = true;
         for (int k = 0; k < 8; ++k) all_voted &= votes[k] >= 1;
@@ -474,7 +482,7 @@ int surfd_mc::run() {
             for (int o = 0; o < 8 && pick < 0; ++o) {
                 const size_t p = vox(cz_[order[o]], cy_[order[o]], cx_[order[o]]);
                 const float *g = gr + 3 * p;
-                if (fixed[p] && (fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2])) > 0) { pick = order[o]; anchor_sign = sgn(sign[p]); }
+                if (is_fixed(p) && (fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2])) > 0) { pick = order[o]; anchor_sign = sgn(sign_of(p)); }
             }
             for (int o = 0; o < 8 && pick < 0; ++o) {
                 const float *g = gr + 3 * vox(cz_[order[o]], cy_[order[o]], cx_[order[o]]);
@@ -491,26 +499,26 @@ int surfd_mc::run() {
                 const size_t p = vox(cz_[k], cy_[k], cx_[k]);
                 const float dp = dot3(base_vec, gr + 3 * p);
                 if (cautious && (double)fabsf(dp) < unsure_thr) { unsure.push_back({z, y, x}); return false; }
-                sign[p] = sgn(dp);
+                set_sign(p, sgn(dp));
             }
         }
         if (grow && probing) return false;          // pre-vote only: no triangles, not finished
         double val[8];
         for (int k = 0; k < 8; ++k) {
             const size_t p = vox(cz_[k], cy_[k], cx_[k]);
-            val[k] = (double)(sign[p] * im[p]);
+            val[k] = (double)(sign_of(p) * im[p]);
         }
         set_cube(x, y, z, val);
-        for (int k = 0; k < 8; ++k) fixed[vox(cz_[k], cy_[k], cx_[k])] = 1;
+        for (int k = 0; k < 8; ++k) state[vox(cz_[k], cy_[k], cx_[k])] |= 4;
         const int mc_case = L.cases.at(pattern, 0);
-        if (mc_case <= 0) { seen[vox(z, y, x)] = 1; return false; }
+        if (mc_case <= 0) { state[vox(z, y, x)] |= 8; return false; }
         if (grow) {
             const bool simple = mc_case == 1 || mc_case == 2 || mc_case == 5 || mc_case == 8 || mc_case == 9;
             if (!simple && (!queue.empty() || !unsure.empty())) { hard.push_back({z, y, x}); return false; }
         }
         const int config = L.cases.at(pattern, 1);
         if (grow && shared_vertices(mc_case, config) < 2) return false;     // must hang on the existing surface
-        seen[vox(z, y, x)] = 1;
+        state[vox(z, y, x)] |= 8;
         triangulate(mc_case, config);
         push_neighbours(z, y, x);
         return true;
@@ -542,7 +550,7 @@ int surfd_mc::run() {
                         c = unsure.front();
                         if (!probing) {
                             // first give the neighbours of an unsure cube a (provisional) vote, then retry the cube itself
-                            if (seen[vox(c.z, c.y, c.x)]) { unsure.pop_front(); continue; }
+                            if (is_seen(vox(c.z, c.y, c.x))) { unsure.pop_front(); continue; }
                             push_neighbours(c.z, c.y, c.x);
                             probing = true;
                             continue;
@@ -634,10 +642,8 @@ int surfd_mc_udf(const float *udf, const float *grads, int nz, int ny, int nx, i
     std::unique_ptr<surfd_mc> m(new surfd_mc());
     m->nx = nx; m->ny = ny; m->nz = nz; m->st = step; m->im = udf; m->gr = grads;
     const size_t n = (size_t)nx * ny * nz;
-    m->sign = (float *)calloc(n, sizeof(float));
-    m->fixed = (unsigned char *)calloc(n, 1);
-    m->seen = (unsigned char *)calloc(n, 1);
-    if (!m->sign || !m->fixed || !m->seen) { surfd::set_error("surfd_mc_udf: out of memory (%zu voxels)", n); return SURFD_ERR_STATE; }
+    m->state = (unsigned char *)calloc(n, 1);
+    if (!m->state) { surfd::set_error("surfd_mc_udf: out of memory (%zu voxels)", n); return SURFD_ERR_STATE; }
     m->cache.reset(new EdgeCache(n));
     m->run();
     m->im = m->gr = nullptr;
