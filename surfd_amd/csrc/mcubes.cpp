@@ -440,7 +440,8 @@ int surfd_mc::run() {
     // Returns true when the cube produced triangles (a seed then starts the growth).
     bool probing = false;             // growth only: the neighbours of an unsure cube are being pre-voted
     auto process = [&](int z, int y, int x, bool grow) -> bool {
-        if (is_seen(vox(z, y, x)) || !near_surface(z, y, x)) return false;
+        const size_t p0 = vox(z, y, x);
+        if (is_seen(p0) || im[p0] > max_thr || !near_surface(z, y, x)) return false;      // (own corner first: it bounds the maximum)
         const int cz_[8] = {z, z, z, z, z + s, z + s, z + s, z + s};
         const int cy_[8] = {y, y, y + s, y + s, y, y, y + s, y + s};
         const int cx_[8] = {x, x + s, x + s, x, x, x + s, x + s, x};
