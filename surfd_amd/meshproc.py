@@ -225,10 +225,17 @@ def vertex_normals_by_angle(vertices: np.ndarray, faces: np.ndarray) -> np.ndarr
 def clean_until_stable(vertices: np.ndarray, faces: np.ndarray, max_iter: int = 10) -> Tuple[np.ndarray, np.ndarray]:
     """meshudf.py:380-404: process + duplicate / degenerate removal + single-hole filling once, then the same cleaning
     (without hole filling) repeated until vertex and face counts stop changing (at most 10 rounds)."""
-    v, f = cull_and_merge(vertices, faces)
-    f = drop_duplicate_faces(f)
+    v, f0 = cull_and_merge(vertices, faces)
+    f = drop_duplicate_faces(f0)
+    n_dedup = len(f)
     f = drop_degenerate_faces(v, f)
+    n_degen = len(f)
     f = fill_small_holes(v, f)
+    if n_dedup == len(f0) and n_degen == n_dedup and len(f) == n_degen:
+        # nothing was removed and no hole was filled (the usual marching-cubes output): every later step of the sequence
+        # is the identity — the culls because all vertices are still referenced and unique, the second duplicate /
+        # degenerate pass because the faces already are in the duplicate pass's key order and all passed the height test
+        return v, f
     v, f = cull_and_merge(v, f)                     # Trimesh(mesh.vertices, mesh.faces) re-processes on construction
     counts, rounds = (0, 0), 0
     while counts != (len(v), len(f)) and rounds < max_iter:

@@ -184,3 +184,24 @@ def test_clean_until_stable_equals_the_unabridged_sequence(seed):
     c, d = _clean_spec(v, f)
     assert np.array_equal(a, c) and np.array_equal(b, d)
     assert np.array_equal(*[x[0] for x in (mp.clean_until_stable(a, b), (a, b))])            # stable: cleaning again changes nothing
+
+
+def test_clean_until_stable_fast_path_on_clean_meshes():
+    """A mesh with nothing to remove and no small hole (what marching cubes usually delivers) leaves the cleaning after
+    the first pass; the result must still be the unabridged sequence's, face order included."""
+    from surfd_amd import mcubes
+    ax = np.linspace(-1, 1, 40, dtype=np.float32)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    vol = np.sqrt(x * x + y * y + (1.3 * z) ** 2) - 0.6
+    for classic in (True, False):
+        v, f = mcubes.marching_cubes(np.ascontiguousarray(vol), 0.0, classic=classic)
+        a, b = mp.clean_until_stable(v, f)
+        c, d = _clean_spec(v, f)
+        assert np.array_equal(a, c) and np.array_equal(b, d)
+        assert len(b) == len(f)                                         # really the fast path: nothing removed
+        # an open mesh (big hole: not filled) and a shuffled one take it too
+        keep = v[f].mean(axis=1)[:, 2] < 25.0
+        perm = np.random.default_rng(3).permutation(int(keep.sum()))
+        a, b = mp.clean_until_stable(v, f[keep][perm])
+        c, d = _clean_spec(v, f[keep][perm])
+        assert np.array_equal(a, c) and np.array_equal(b, d)
