@@ -205,3 +205,61 @@ def test_clean_until_stable_fast_path_on_clean_meshes():
         a, b = mp.clean_until_stable(v, f[keep][perm])
         c, d = _clean_spec(v, f[keep][perm])
         assert np.array_equal(a, c) and np.array_equal(b, d)
+
+
+# ---- randomised invariants (hypothesis): what must hold for ANY mesh, whatever trimesh's exact face order would be -----
+from hypothesis import given, settings, strategies as st    # noqa: E402
+
+
+@st.composite
+def _meshes(draw):
+    n = draw(st.integers(4, 40))
+    m = draw(st.integers(1, 80))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    v = np.round(rng.normal(size=(n, 3)), draw(st.integers(0, 3)))          # coarse rounding makes coincident vertices likely
+    f = rng.integers(0, n, size=(m, 3))
+    return v, f
+
+
+@settings(max_examples=60, deadline=None)
+@given(_meshes())
+def test_cull_and_merge_invariants(mesh):
+    v, f = mesh
+    nv, nf = mp.cull_and_merge(v, f)
+    assert len(nf) == len(f)                                                 # faces are re-indexed, never dropped
+    np.testing.assert_allclose(nv[nf], v[f], atol=mp.MERGE_TOL)               # every corner keeps its position
+    assert len(np.unique(np.round(nv / mp.MERGE_TOL).astype(np.int64), axis=0)) == len(nv)    # survivors are distinct
+    assert set(np.unique(nf)) == set(range(len(nv)))                         # and all referenced
+    v2, f2 = mp.cull_and_merge(nv, nf)
+    assert np.array_equal(v2, nv) and np.array_equal(f2, nf)                 # idempotent
+
+
+@settings(max_examples=60, deadline=None)
+@given(_meshes())
+def test_duplicate_and_component_invariants(mesh):
+    v, f = mesh
+    g = mp.drop_duplicate_faces(f)
+    keys = {tuple(sorted(t)) for t in f.tolist()}
+    assert len(g) == len(keys) and {tuple(sorted(t)) for t in g.tolist()} == keys          # one face per vertex triple
+    assert np.array_equal(mp.drop_duplicate_faces(g), g)                                  # idempotent, order included
+    # connected components against a plain union-find over shared vertices
+    parent = list(range(len(v)))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for a, b, c in f.tolist():
+        ra, rb, rc = find(a), find(b), find(c)
+        parent[rb] = ra
+        parent[find(rc)] = ra
+    want = [find(t[0]) for t in f.tolist()]
+    lab = mp.face_components(f, len(v))
+    assert len(set(zip(want, lab.tolist()))) == len(set(want)) == len(set(lab.tolist()))   # same partition of the faces
+    # the size filter keeps exactly the faces of large enough components
+    sizes = {r: want.count(r) for r in set(want)}
+    k = max(sizes.values())
+    kv, kf = mp.keep_components_with_at_least(v, f, k)
+    assert len(kf) == sum(s for s in sizes.values() if s >= k)
