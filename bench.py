@@ -1,30 +1,39 @@
 #!/usr/bin/env python3
-"""Headline benchmark: shapes/sec end-to-end for unconditional Surf-D sampling.
+"""Headline benchmark: shapes/sec end-to-end for Surf-D sampling.
 
-One "step" = one pass of the hot path over one batch of synthetic shapes on every rank:
-    noise -> 1000-step DDPM reverse loop over the latent denoiser (B shapes at once)
-          -> per shape: coarse-to-fine UDF grid (N^3) + spatial gradient, resident in HBM
-(end point E1 of SURVEY.md §8d).  Weights are the deterministic synthetic tensors of
-surfd_amd.synth (no checkpoints exist offline); noise is seeded per global shape index, so a
-shape's result does not depend on how shapes are sharded over ranks.
+One "step" = one pass of the hot path over one batch of B (8) synthetic shapes on every rank:
+    noise -> 1000-step DDPM reverse loop over the latent denoiser
+          -> per shape: coarse-to-fine UDF grid (N^3) + spatial gradient, resident in HBM          (end point E1)
+          -> [--endpoint e2] near-surface band compacted on the device, copied to pinned host memory on a copy stream
+             and meshed by the native UDF marching cubes on host threads, every mesh finished inside the timed region
+Weights are the deterministic synthetic tensors of surfd_amd.synth (no checkpoints exist offline).  Every step of every
+rank works on DIFFERENT shapes: noise (and conditioning) is seeded per global shape index
+((step * world + rank) * B + k), so a shape's result depends neither on the sharding nor on the schedule.
 
     python bench.py --gpus 1 --steps 6 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Batches are software-pipelined (--pipeline 1, default; surfd_amd.parallel.BatchPipeline): one reverse loop is a chain
-of ~100 000 dependent, latency-bound launches that fills a fraction of the chip, so --loop-chains loops of DIFFERENT
-batches run concurrently (own stream + execution context each) next to the grid evaluation (matrix-pipe bound) of an
-older batch on --decoder-blocks of the CUs.  Every one of the K batches runs start to finish inside the timed region
-(pipeline fill and drain included).  --pipeline 0 runs loop then grids on one stream.
+Schedules (--schedule):
+  phased (default)  time-sliced: the reverse loops of a ROUND of steps first, as --loop-chains wide loops at once (each
+                    over up to --loop-batches steps' latents: the denoiser's 553 MB of weights are streamed once per
+                    evaluation for all of them; conv kernel in its wide form), the whole chip theirs; then the grids of
+                    the round, the decoder's persistent workgroups on every CU (surfd_amd.parallel.PhasedPipeline)
+  overlap           round 2's software pipeline: --loop-chains narrow loops of different steps on a quarter of the chip
+                    next to the grids of an older step (surfd_amd.parallel.BatchPipeline)
+  sequential        loop, then grids, step after step on one stream
+Every step runs start to finish inside the timed region in every schedule.
 
-The JSON line also carries: `roofline` (dominant kernel = forward decoder, ALGORITHMIC flops vs the
-fp16 matrix peak; the issued figure beside it), `roofline_loop` (denoiser weight stream vs HBM), `w_trace` (the decoder
-kernels timed on the thin-shell query trace of a trained-model-like field), `e2` (through marching cubes, host side)
-and `cpu_baseline` (the oracle on this host's cores, bounded sample).
+Configurations (--config; BASELINE.json configs[1..4], one GPU's share): c3 (default, the metric's: unconditional, L=32,
+512^3), c2 (same at 256^3), c4 (text-conditioned: per-shape context, classifier-free wrapper with scale 3.0, L=64, D=64,
+512^3), c5 (image-conditioned: per-shape context, L=64, D=64, 512^3).  --workload trace replaces the synthetic decoder's
+own coarse-to-fine queries (8.3 % of 512^3) by the query lists of a trained-model-like thin shell (1.5 %), loops included.
 
-Multi-GPU: shapes are independent -> each rank owns its own B shapes (weak scaling), no
-data-path collective; ranks meet only at the timing barriers.
-Prints ONE JSON line on rank 0.
+The JSON line carries: `roofline` (the kernel with the most GPU time = forward decoder: ALGORITHMIC flops
+vs the fp16 matrix peak, the issued figure beside it), `roofline_loop` (denoiser weight stream vs HBM), `time_share`,
+`w_trace`, `e2`, `cpu_baseline` (the oracle on this host's cores, bounded sample), and for N > 1 `per_rank`.
+Multi-GPU: shapes are independent -> each rank owns its own B shapes per step (weak scaling), no data-path collective;
+ranks meet only at the timing barriers.  --mode grid-shard instead splits every level of ONE shape's grid over the ranks
+(device-side counts, ncclAllGather of the values over xGMI).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -56,35 +65,71 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c3",
+                    help="BASELINE.json configs[1..4], per-GPU share (c3 = the metric's configuration)")
     ap.add_argument("--batch", type=int, default=8, help="shapes per GPU per step")
-    ap.add_argument("--resolution", type=int, default=512)
+    ap.add_argument("--resolution", type=int, default=None, help="grid resolution (default: the config's, 512 / 256 for c2)")
     ap.add_argument("--diffusion-steps", type=int, default=1000, help="1000 = full DDPM chain (the metric)")
-    ap.add_argument("--latent", type=int, default=32)
+    ap.add_argument("--latent", type=int, default=None, help="latent length (default: the config's, 32 / 64 for c4, c5)")
     ap.add_argument("--decoder-precision", choices=["f16x2", "fp32"], default="f16x2",
-                    help="forward decoder kernel arithmetic (include/surfd_hip.h: surfd_decoder_set_precision)")
-    ap.add_argument("--decoder-blocks", type=int, default=192,
-                    help="with --pipeline 1: persistent decoder workgroups per launch while the next batch's reverse loop "
-                         "runs on the remaining CUs (the last batch's grids, with nothing left to overlap, use every CU)")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="1: overlap the reverse loops of the next batches with the grid evaluation of the current one")
-    ap.add_argument("--loop-chains", type=int, default=3,
-                    help="with --pipeline 1: reverse loops (of different batches) in flight at once, each on its own stream "
-                         "and execution context (MDM.replica)")
-    ap.add_argument("--loop-cus", type=int, default=64,
-                    help="pipeline mode: the CU budget each reverse loop sizes its split-K for (MDM.set_cu_budget); 256 = as if alone")
+                    help="decoder kernel arithmetic (include/surfd_hip.h: surfd_decoder_set_precision)")
     ap.add_argument("--unet-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="denoiser conv arithmetic (include/surfd_hip.h: surfd_unet_set_precision)")
+    ap.add_argument("--schedule", choices=["phased", "overlap", "sequential"], default="phased")
+    ap.add_argument("--pipeline", type=int, default=None, help="(round-2 flag) 1 = --schedule overlap, 0 = --schedule sequential")
+    ap.add_argument("--loop-chains", type=int, default=None,
+                    help="reverse loops in flight at once, each on its own stream and execution context (MDM.replica); "
+                         "default 2 (phased) / 3 (overlap)")
+    ap.add_argument("--loop-batches", type=int, default=10,
+                    help="phased: steps whose latents ride in ONE wide reverse loop (10 x 8 = 80 latents per loop)")
+    ap.add_argument("--wide-design-batch", type=int, default=32,
+                    help="phased: design batch of the conv kernel's wide form (MDM.set_wide); the K split, hence the bits, depend on it, not on the loop width")
+    ap.add_argument("--decoder-blocks", type=int, default=192,
+                    help="overlap: persistent decoder workgroups per launch while loops run on the remaining CUs")
+    ap.add_argument("--loop-cus", type=int, default=64,
+                    help="overlap: the CU budget each reverse loop sizes its split-K for (MDM.set_cu_budget)")
     ap.add_argument("--workload", choices=["real", "trace"], default="real",
-                    help="real: coarse-to-fine grids of the synthetic decoder (the headline); trace: the decoder kernels over the "
-                         "query lists a trained-model-like thin-shell field produces (SURVEY.md §8d W-trace)")
+                    help="real: coarse-to-fine grids of the synthetic decoder (the headline); trace: reverse loops + the decoder "
+                         "kernels over the query lists a trained-model-like thin-shell field produces (SURVEY.md §8d W-trace), end to end")
+    ap.add_argument("--endpoint", choices=["e1", "e2"], default="e1",
+                    help="e1: grids + gradients resident in HBM (the metric's end point); e2: through marching cubes, every mesh "
+                         "finished inside the timed region (band compaction on the device, pinned D2H, host mesher threads)")
+    ap.add_argument("--mesh-threads", type=int, default=0, help="e2: host meshing threads per rank (0 = min(8, cores / ranks - chains))")
+    ap.add_argument("--mode", choices=["shape-parallel", "grid-shard"], default="shape-parallel",
+                    help="grid-shard: every level of one shape's grid split over the ranks (needs --gpus >= 2 to mean anything)")
     ap.add_argument("--batch-grids", type=int, default=1,
-                    help="1: the grids of a batch are refined together, one decoder launch per level for all shapes "
+                    help="1: the grids of a step are refined together, one decoder launch per level for all shapes "
                          "(meshudf.fill_grids); 0: shape after shape")
-    ap.add_argument("--timeline", action="store_true", help="print per-batch loop / grid completion times of the timed region to stderr")
+    ap.add_argument("--timeline", action="store_true", help="print per-round loop / grid completion times of the timed region to stderr")
     ap.add_argument("--no-trace", action="store_true", help="skip the untimed W-trace measurement")
-    ap.add_argument("--no-e2", action="store_true", help="skip the E2 (through marching cubes) estimate")
+    ap.add_argument("--no-e2", action="store_true", help="skip the untimed E2 stage figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    if a.resolution is None:
+        a.resolution = cfg["resolution"]
+    if a.latent is None:
+        a.latent = cfg["latent"]
+    if a.pipeline is not None:
+        a.schedule = "overlap" if a.pipeline else "sequential"
+    if a.loop_chains is None:
+        a.loop_chains = 3 if a.schedule == "overlap" else 2
+    return a
+
+
+# BASELINE.json configs[1..4] as one GPU's share (C2..C5)
+CONFIGS = {
+    "c2": {"cond_mode": "no_cond", "latent": 32, "resolution": 256, "cfg": False,
+           "name": "C2 = BASELINE configs[1]: unconditional, 256^3, batch 8 on one GPU"},
+    "c3": {"cond_mode": "no_cond", "latent": 32, "resolution": 512, "cfg": False,
+           "name": "C3 = BASELINE configs[2]: unconditional, 512^3, 8 shapes per GPU (the per-GPU shard of batch 64 over 8 GPUs)"},
+    "c4": {"cond_mode": "text", "latent": 64, "resolution": 512, "cfg": True,
+           "name": "C4 = BASELINE configs[3]: text-conditioned (per-shape 512-d context in place of the CLIP text tower, "
+                   "classifier-free wrapper, scale 3.0), L=64, 512^3, 8 shapes per GPU"},
+    "c5": {"cond_mode": "img", "latent": 64, "resolution": 512, "cfg": False,
+           "name": "C5 = BASELINE configs[4]: image-conditioned (per-shape 512-d context in place of the CLIP image tower), L=64, 512^3, "
+                   "8 shapes per GPU"},
+}
 
 
 def self_launch(n_gpus):
@@ -123,25 +168,6 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-def build_models(latent, precision, unet_precision="f16x2"):
-    from surfd_amd import synth
-    from surfd_amd.cbndec import CbnDecoder
-    from surfd_amd.mdm import create_model_and_diffusion, load_model_wo_clip
-    from surfd_amd.spec import DecoderConfig
-    args = types.SimpleNamespace(cond_mode="no_cond", arch="OpenUNet", num_actions=9, dataset="deepfashion3d",
-                                 noise_schedule="cosine", sigma_small=True, clip_value=1.0)
-    model, diffusion = create_model_and_diffusion(args)
-    load_model_wo_clip(model, synth.synth_unet_state_dict())
-    model.to("cuda")
-    model.eval()
-    model.set_precision(unet_precision)
-    dec = CbnDecoder(63, latent, 512, 5)
-    dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig(latent_dim=latent)), strict=True)
-    dec = dec.cuda().eval()
-    dec.set_precision(precision)
-    return model, diffusion, dec
-
-
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -152,7 +178,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(T, B, n_fwd, n_grad):
+def cpu_baseline(T, B, n_fwd, n_grad, latent=32):
     """The oracle (CPU restatement of the reference's op graph) timed on this host on a bounded
     sample of the same workload, scaled to shapes/s: a few denoiser steps at batch B, forward decoder
     queries and forward+backward queries at the two chunk sizes the reference scripts use (the faster is quoted)."""
@@ -163,7 +189,7 @@ def cpu_baseline(T, B, n_fwd, n_grad):
     # 32 threads was the fastest setting for this op mix; "cores" reports what was actually used
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     sd = synth.synth_unet_state_dict()
-    x = torch.randn(B, 1, 32)
+    x = torch.randn(B, 1, latent)
     t = torch.full((B,), 500)
     with torch.no_grad():
         ounet.unet_forward(sd, x, t)
@@ -172,8 +198,9 @@ def cpu_baseline(T, B, n_fwd, n_grad):
         for _ in range(n_it):
             ounet.unet_forward(sd, x, t)
         step_s = (time.time() - t0) / n_it
-    dsd = synth.synth_decoder_state_dict()
-    f = odec.make_udf_func(dsd, torch.randn(1, 32) * 0.8)
+    from surfd_amd.spec import DecoderConfig
+    dsd = synth.synth_decoder_state_dict(DecoderConfig(latent_dim=latent))
+    f = odec.make_udf_func(dsd, torch.randn(1, latent) * 0.8)
     pts = torch.rand(16384, 3) * 2 - 1
     odec.sample_udf(f, pts[:4096], 4096)
     rates = {}
@@ -264,87 +291,162 @@ def committed_traffic():
     return None
 
 
+def build_models(cfg, latent, precision, unet_precision="f16x2"):
+    """(denoiser, diffusion, decoder) for a configuration: synthetic weights in the reference's checkpoint layouts."""
+    from surfd_amd import synth
+    from surfd_amd.cbndec import CbnDecoder
+    from surfd_amd.mdm import create_model_and_diffusion, load_model_wo_clip
+    from surfd_amd.spec import DecoderConfig
+    # the conditioned denoisers are built as the image model (sketch/img/text share the architecture: a 512-d context
+    # enters through sketch_emb, models/mdm.py:91-110); text mode is then selected on the module, as
+    # sample/generate_text.py gets it from its checkpoint's args
+    build_mode = "no_cond" if cfg["cond_mode"] == "no_cond" else "img"
+    args = types.SimpleNamespace(cond_mode=build_mode, arch="OpenUNet", num_actions=9, dataset="deepfashion3d",
+                                 noise_schedule="cosine", sigma_small=True, clip_value=1.0)
+    model, diffusion = create_model_and_diffusion(args)
+    load_model_wo_clip(model, synth.synth_unet_state_dict())
+    model.to("cuda")
+    model.eval()
+    model.cond_mode = cfg["cond_mode"]
+    model.set_precision(unet_precision)
+    dec = CbnDecoder(63, latent, 512, 5)
+    dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig(latent_dim=latent)), strict=True)
+    dec = dec.cuda().eval()
+    dec.set_precision(precision)
+    return model, diffusion, dec
+
+
 def main():
     a = parse()
     world, rank, local = setup_dist(a.gpus)
+    if a.mode == "grid-shard":
+        return grid_shard_main(a, world, rank)
     from surfd_amd import _native as Nn
     from surfd_amd import synth
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
     from surfd_amd.meshudf import fill_grids as fill_grids_batch
+    from surfd_amd.parallel import BatchPipeline, PhasedPipeline
     L = Nn.lib()
-    model, diffusion, dec = build_models(a.latent, a.decoder_precision, a.unet_precision)
+    cfg = CONFIGS[a.config]
+    model, diffusion, dec = build_models(cfg, a.latent, a.decoder_precision, a.unet_precision)
     if a.diffusion_steps != 1000:
         from surfd_amd.diffusion import create_gaussian_diffusion
         diffusion = create_gaussian_diffusion(types.SimpleNamespace(noise_schedule="cosine", sigma_small=True),
                                               f"ddim{a.diffusion_steps}")
     T, B, N = diffusion.num_timesteps, a.batch, a.resolution
-    first = rank * B                                     # global index of this rank's first shape
-    noise = synth.synth_noise_batch(T, first, B, a.latent).cuda()
+    conditioned = cfg["cond_mode"] != "no_cond"
+    n_steps_max = max(a.steps, a.warmup, 1)
+    # global shape index of (step s, rank, k): every step of every rank samples different shapes
+    gidx = lambda s: (s * world + rank) * B
+    noise_bank = torch.stack([synth.synth_noise_batch(T, gidx(s), B, a.latent) for s in range(n_steps_max)], 0).cuda()   # [S, T+1, B, 1, L]
+    ctx_bank = torch.stack([synth.synth_context(gidx(s), B) for s in range(n_steps_max)], 0).cuda() if conditioned else None
+    sampler_model = model
+    if cfg["cfg"]:
+        from surfd_amd.mdm import ClassifierFreeSampleModel
+
+    def loop_kwargs(first, n):
+        if not conditioned:
+            return {"y": {}}
+        y = {"context": ctx_bank[first:first + n].reshape(n * B, -1).contiguous()}
+        if cfg["cfg"]:
+            y["scale"] = torch.full((n * B,), 3.0, device="cuda")
+        return {"y": y}
+
     filler = GridFiller(N)
-    fillers = [filler] + [GridFiller(N) for _ in range(B - 1)] if a.batch_grids and B <= 8 else None
+    fillers = [filler] + [GridFiller(N) for _ in range(B - 1)] if a.batch_grids and B <= 8 else [filler]
     udf = [torch.empty(N, N, N, device="cuda") for _ in range(B)]
     grads = [torch.empty(N, N, N, 3, device="cuda") for _ in range(B)]
-    stats = []
     trace = make_trace(N) if a.workload == "trace" else None
 
-    chains = [model] + [model.replica() for _ in range(max(1, a.loop_chains) - 1)] if a.pipeline else [model]
+    n_chains = max(1, a.loop_chains) if a.schedule != "sequential" else 1
+    chains = [model] + [model.replica() for _ in range(n_chains - 1)]
     for m in chains[1:]:
         m.set_precision(a.unet_precision)
-    if a.pipeline:
+    # a conditioned loop keeps one embedding row per (iteration, latent): 56 KB x T x latents -> narrower loops
+    loop_batches = a.loop_batches if not conditioned else max(1, min(a.loop_batches, 16 // max(1, B // 8)))
+    if a.schedule == "phased":
+        for m in chains:
+            m.set_wide(a.wide_design_batch)
+    elif a.schedule == "overlap":
         for m in chains:
             m.set_cu_budget(a.loop_cus)
+    wrapped = [ClassifierFreeSampleModel(m) if cfg["cfg"] else m for m in chains]
 
-    def sample_latents(chain=0):
-        return diffusion.p_sample_loop(chains[chain], (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}},
+    def sample_latents(first, n, chain=0):
+        """ONE reverse loop over the latents of steps [first, first + n) -> [n * B, 1, L]"""
+        noise = noise_bank[first:first + n].permute(1, 0, 2, 3, 4).reshape(T + 1, n * B, 1, a.latent).contiguous()
+        return diffusion.p_sample_loop(wrapped[chain], (n * B, 1, a.latent), clip_denoised=False, model_kwargs=loop_kwargs(first, n),
                                        noise_stream=noise, fused=True)
 
-    def fill_grids(lat, collect=False):
+    mesher = None
+    if a.endpoint == "e2":
+        from surfd_amd.mcubes import BandMesher
+        threads = a.mesh_threads or max(1, min(8, (os.cpu_count() or 8) // world - n_chains))
+        mesher = BandMesher(N, threads=threads, slots=2 * B)
+
+    def fill_grids(step, lat):
         dec.bind_latents(lat.reshape(B, a.latent))
-        if fillers is not None and trace is None:
-            # all shapes of the batch level by level together: one persistent decoder launch per level (meshudf.fill_grids)
-            fill_grids_batch(fillers, dec, list(range(B)), [(udf[k], grads[k]) for k in range(B)])
-            if collect:
-                stats.extend(f._stats() for f in fillers)
-            return
-        for k in range(B):
-            if trace is not None:                        # W-trace: the decoder kernels over the trained-model-like query lists
+        if trace is not None:                            # W-trace: the decoder kernels over the trained-model-like query lists
+            for k in range(B):
                 for kind, c in trace:
                     (dec.udf if kind == "fwd" else dec.udf_and_ngrad)(c, k)
-                continue
-            f = make_udf_func(dec, lat[k], sample=k)
-            filler.fill_grid(f, 2 ** 16, out=(udf[k], grads[k]), stats=collect)
-            if collect:
-                stats.append(filler.last_stats)
+            return
+        if len(fillers) == B:
+            # all shapes of the step level by level together: one persistent decoder launch per level (meshudf.fill_grids)
+            fill_grids_batch(fillers, dec, list(range(B)), [(udf[k], grads[k]) for k in range(B)])
+        else:
+            for k in range(B):
+                filler.fill_grid(make_udf_func(dec, lat[k], sample=k), 2 ** 16, out=(udf[k], grads[k]), stats=False)
+        if mesher is not None:
+            for k in range(B):
+                mesher.submit(udf[k], grads[k], tag=(step, k))     # device-side band compaction + async D2H; meshing on host threads
 
-    def one_step(collect=False):
-        lat = sample_latents()
-        fill_grids(lat, collect)
-        return lat
-
-    from surfd_amd.parallel import BatchPipeline
-    pipe = BatchPipeline(dec, lambda s, q: sample_latents(q), lambda s, lat: fill_grids(lat), a.decoder_blocks,
-                         loop_chains=len(chains))
+    if a.schedule == "phased":
+        pipe = PhasedPipeline(sample_latents, fill_grids, chains=n_chains, max_loop_batches=loop_batches)
+    elif a.schedule == "overlap":
+        pipe = BatchPipeline(dec, lambda s, q: sample_latents(s, 1, q), fill_grids, a.decoder_blocks, loop_chains=n_chains)
+    else:
+        pipe = None
 
     def run_steps(k_steps):
-        """k_steps full passes (every batch: reverse loop + B grids), start to finish."""
-        if not a.pipeline:
-            for _ in range(k_steps):
-                one_step()
-        elif k_steps:
+        """k_steps full passes (every step: reverse loop + B grids [+ B meshes]), start to finish."""
+        if k_steps <= 0:
+            return
+        if pipe is None:
+            for s in range(k_steps):
+                fill_grids(s, sample_latents(s, 1))
+        else:
             pipe.run(k_steps)
+        if mesher is not None:
+            mesher.drain()                                # every mesh of the job is finished
+
+    def reset_totals():
+        if trace is None:
+            for f in fillers:
+                if f._handle is not None:
+                    f.totals(reset=True)
+        if mesher is not None:
+            mesher.reset_stats()
 
     run_steps(a.warmup)
-    pipe.record_timeline = a.timeline
+    if pipe is not None:
+        pipe.record_timeline = a.timeline or world > 1
+    torch.cuda.synchronize()
+    reset_totals()
     barrier(world)
     L.surfd_profile_enable(1)
     t0 = time.perf_counter()
     run_steps(a.steps)
+    torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     barrier(world)
     elapsed = time.perf_counter() - t0
-    if a.timeline and a.pipeline:
-        for m in pipe.timeline:
-            print("[timeline] batch %2d: loop done %8.1f ms, grids %8.1f -> %8.1f ms" % (m["batch"], m["loop_done_ms"], m["grids_start_ms"], m["grids_done_ms"]), file=sys.stderr)
+    timeline = list(pipe.timeline) if pipe is not None and pipe.record_timeline else []
+    if a.timeline:
+        for m in timeline:
+            print("[timeline] " + json.dumps(m), file=sys.stderr)
+    if pipe is not None:
         pipe.record_timeline = False
     L.surfd_profile_enable(0)
     prof = {}
@@ -352,28 +454,44 @@ def main():
         n, ms = C.c_int64(), C.c_double()
         Nn.check(L.surfd_profile_read(kind, C.byref(n), C.byref(ms)))
         prof[name] = (n.value, ms.value)
-    # ---- untimed extras: workload counters (deterministic), one loop alone, the trace workload -------------
+    # ---- exact query counts of the timed region (kept on the device by the fills themselves) ----------------------
+    if trace is None:
+        tot = [f.totals(reset=True) for f in fillers]
+        fwd_total = float(sum(sum(t["fwd_per_level"]) for t in tot))
+        grad_total = float(sum(t["grad"] for t in tot))
+        assert sum(t["fills"] for t in tot) == B * a.steps, (sum(t["fills"] for t in tot), B * a.steps)
+    else:
+        fwd_total = float(sum(c.shape[0] for k, c in trace if k == "fwd")) * B * a.steps
+        grad_total = float(sum(c.shape[0] for k, c in trace if k == "grad")) * B * a.steps
+    n_fwd, n_grad = fwd_total / (B * a.steps), grad_total / (B * a.steps)
+    mesh_stats = mesher.stats() if mesher is not None else None
+    # ---- untimed extras: one loop alone at the widest batch the schedule used --------------------------------------
     dec.set_grid_blocks(0)
-    if a.pipeline and a.loop_cus != 256:
+    if a.schedule == "overlap" and a.loop_cus != 256:
         model.set_cu_budget(256)                         # one loop alone owns the chip
-        sample_latents()                                 # re-capture outside the timed call
+    alone_n = min(loop_batches, max(1, -(-a.steps // n_chains))) if a.schedule == "phased" else 1
+    alone_n = min(alone_n, n_steps_max)
+    lat = sample_latents(0, alone_n)                     # (re-)capture outside the timed call
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    lat = sample_latents()
+    lat = sample_latents(0, alone_n)
     torch.cuda.synchronize()
     loop_alone_ms = (time.perf_counter() - t1) * 1e3
-    if trace is None:
-        fill_grids(lat, collect=True)
-        torch.cuda.synchronize()
-        n_fwd = sum(sum(s["fwd_per_level"]) for s in stats) / B
-        n_grad = sum(s["grad"] for s in stats) / B
-    else:
-        n_fwd = sum(c.shape[0] for k, c in trace if k == "fwd")
-        n_grad = sum(c.shape[0] for k, c in trace if k == "grad")
+    lat = lat[:B]
     sat = sum(m.saturation_count() for m in chains) + dec.saturation_count()
     rccl_ranks = 1
+    per_rank = None
     if world > 1:
         import torch.distributed as dist
+        fwd_l, fwd_m = prof["dec_fwd"]; grd_l, grd_m = prof["dec_grad"]; lp_n, lp_m = prof["loop"]
+        loops_done = max((m.get("loops_done_ms", 0.0) for m in timeline), default=0.0)
+        mine = torch.tensor([local_elapsed * 1e3, lp_m, fwd_m, grd_m, loops_done, fwd_total, float(os.cpu_count() or 0)],
+                            device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": float(v[0]) / a.steps, "loop_latency_ms_sum": float(v[1]), "decoder_fwd_ms": float(v[2]),
+                     "decoder_fwd_bwd_ms": float(v[3]), "last_round_loops_done_ms": float(v[4]), "decoder_fwd_queries": float(v[5])}
+                    for r, v in enumerate(allr)]
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -383,16 +501,17 @@ def main():
     if rank != 0:
         return
     w_trace = None
-    if not a.no_trace and rank == 0:
+    if not a.no_trace:
         del udf, grads
+        if mesher is not None:
+            mesher.close()
         torch.cuda.empty_cache()
         w_trace = time_trace(dec, lat, trace if trace is not None else make_trace(N))
     shapes = world * B * a.steps
     fwd_launches, fwd_ms = prof["dec_fwd"]
     grad_launches, grad_ms = prof["dec_grad"]
     loops, loop_ms = prof["loop"]
-    fwd_flop_total = n_fwd * B * a.steps * FWD_FLOP            # this rank, timed region
-    algorithmic = fwd_flop_total / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+    algorithmic = fwd_total * FWD_FLOP / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
     f16 = a.decoder_precision == "f16x2"
     peak = F16_MFMA_PEAK_TF if f16 else FP32_MFMA_PEAK_TF
     kname = ("decoder_kernel<false, f16x2> (fused encode + 11-layer CBN MLP + sigmoid; split-fp16 operands, fp32 accumulate)"
@@ -401,65 +520,85 @@ def main():
              "accumulation — fp32-class error, same golden tolerances as the exact-fp32 kernels; samplers, attention, "
              "embedding MLP and grid bookkeeping in exact fp32)") if f16 and a.unet_precision == "f16x2" else "f32"
     pmc = committed_traffic()
-    # reverse loop against its roofline: per evaluation max(weight bytes / HBM, B * flops / matrix peak)
-    flops_eval = B * UNET_FLOP_PER_SAMPLE.get(a.latent, 2.057e9 * a.latent / 32)
+    # reverse loop against its roofline: per evaluation max(weight bytes / HBM, latents * flops / matrix peak)
+    lat_per_loop = alone_n * B
+    flops_eval = lat_per_loop * UNET_FLOP_PER_SAMPLE.get(a.latent, 2.057e9 * a.latent / 32)
     unet_peak = F16_MFMA_PEAK_TF / 3.0 if a.unet_precision == "f16x2" else FP32_MFMA_PEAK_TF      # algorithmic flops / s
     roof_eval_us = max(UNET_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e9), flops_eval / (unet_peak * 1e12)) * 1e6
-    streamed_gbs = loops * T * UNET_WEIGHT_BYTES / elapsed / 1e9                  # all chains, whole timed region
+    # time the loops had the chip: phased = up to the last loop of each round; otherwise they overlap the grids
+    if a.schedule == "phased" and timeline:
+        prev, loop_phase_ms = 0.0, 0.0
+        for m in timeline:
+            loop_phase_ms += m["loops_done_ms"] - prev
+            prev = m["grids_done_ms"]
+    else:
+        loop_phase_ms = None
+    streamed_gbs = loops * T * UNET_WEIGHT_BYTES / ((loop_phase_ms * 1e-3) if loop_phase_ms else elapsed) / 1e9
+    sched = {"phased": (f"time-sliced rounds: the reverse loops of up to {n_chains} x {loop_batches} steps as {n_chains} wide loops at once (conv kernel in "
+                        f"its wide form, K split designed for {a.wide_design_batch} latents), the whole chip theirs, then the round's grids with the decoder's "
+                        "persistent workgroups on every CU; every step runs start to finish inside the timed region"),
+             "overlap": (f"{n_chains} reverse loops of different steps in flight (own stream + context each, split-K sized for {a.loop_cus} CUs) next to the grids "
+                         f"of an older step on {a.decoder_blocks} of the 256 CUs"),
+             "sequential": "none (loop then grids, one stream)"}[a.schedule]
     out = {
         "metric": "shapes/sec end-to-end (1000-step uncond, 512^3 UDF) at 1/2/4/8 GPU",
         "value": shapes / elapsed, "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype, "data": "synthetic (seeded random-init weights of the reference architectures, seeded noise)",
+        "dtype": dtype, "data": "synthetic (seeded random-init weights of the reference architectures, seeded noise" + (", seeded context vectors" if conditioned else "") + "; different shapes in every step)",
         "rccl_ranks": rccl_ranks,
-        "config": {"workload": f"unconditional, {T}-step {'DDPM' if a.diffusion_steps == 1000 else 'DDIM'}, L={a.latent}, "
-                               + (f"{N}^3 coarse-to-fine UDF grid + gradients (end point E1: grids resident in HBM), W-real: the "
-                                  "synthetic decoder's own occupancy" if trace is None else
-                                  f"W-trace: decoder over the {N}^3 thin-shell query lists (2.05 M fwd + 0.75 M grad per shape)")
-                               + f", {B} shapes/GPU (BASELINE configs[2] per-GPU shard)",
-                   "shapes_per_gpu": B, "resolution": N, "diffusion_steps": T,
+        "config": {"workload": f"{cfg['name']}; {T}-step {'DDPM' if a.diffusion_steps == 1000 else 'DDIM'}, L={a.latent}, "
+                               + (f"{N}^3 coarse-to-fine UDF grid + gradients, W-real: the synthetic decoder's own occupancy" if trace is None else
+                                  f"W-trace: reverse loops + decoder over the {N}^3 thin-shell query lists of a trained-model-like field")
+                               + (", end point E1 (grids resident in HBM)" if a.endpoint == "e1" else ", end point E2 (through marching cubes: every mesh finished inside the timed region)"),
+                   "baseline_config": a.config, "endpoint": a.endpoint,
+                   "shapes_per_gpu": B, "resolution": N, "diffusion_steps": T, "latent": a.latent,
                    "decoder_fwd_queries_per_shape": n_fwd, "decoder_grad_queries_per_shape": n_grad,
                    "decoder_precision": a.decoder_precision, "unet_precision": a.unet_precision,
                    "fp16_range_saturations": sat,
-                   "pipeline": (f"{len(chains)} reverse loops of different batches in flight (own stream + context each) next to the "
-                                f"grids of an older batch (each loop sizes its split-K for {a.loop_cus} CUs); the decoder kernels run on {a.decoder_blocks} of the 256 CUs while loops "
-                                "are in flight and on all of them for the last round of batches; every batch runs start to finish inside the "
-                                "timed region") if a.pipeline else "none (loop then grids, one stream)",
+                   "schedule": a.schedule, "pipeline": sched,
+                   "host_threads_per_rank": {"loop_chains": n_chains, "meshing": (mesh_stats or {}).get("threads", 0), "host_cores": os.cpu_count(), "ranks": world},
                    "parallelism": f"shape-parallel x{world}, no data-path collective (latents all_gathered after the timed region)"},
         "roofline": {"kernel": kname, "bound": "mfma",
                      "achieved": algorithmic, "peak": peak, "unit": "TFLOP/s", "frac": algorithmic / peak,
                      "traffic": (pmc or {}).get("decoder_fwd_hbm_bytes_per_launch"),
-                     "traffic_source": (pmc or {}).get("source"),
-                     "algorithmic_bytes_per_launch": 16.0 * n_fwd * B * a.steps / max(fwd_launches, 1),
+                     "traffic_from": "committed profile (not a counter of this run): " + str((pmc or {}).get("source")),
+                     "algorithmic_bytes_per_launch": 16.0 * fwd_total / max(fwd_launches, 1),
                      "launches": fwd_launches, "avg_launch_ms": fwd_ms / max(fwd_launches, 1),
                      "flop_per_point": FWD_FLOP,
                      "issued_tflops": (3.0 if f16 else 1.0) * algorithmic, "issued_frac": (3.0 if f16 else 1.0) * algorithmic / peak,
-                     "cus": (f"{a.decoder_blocks} of 256 while loops are in flight, 256 for the last round of batches; peak is the whole chip's")
-                            if a.pipeline else "256"},
-        "roofline_loop": {"kernel": "conv2_kernel<8,false> x84 + attn_kernel x16 per denoiser evaluation (hipGraph replay)",
+                     "cus": (f"{a.decoder_blocks} of 256 while loops are in flight, 256 for the last round; peak is the whole chip's")
+                            if a.schedule == "overlap" else "256"},
+        "roofline_loop": {"kernel": "conv2_kernel x84 + attn_kernel x16 + 2 step kernels per denoiser evaluation (hipGraph replay)",
                           "bound": "hbm", "achieved": streamed_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": streamed_gbs / HBM_PEAK_GBS,
                           "traffic": (pmc or {}).get("unet_eval_hbm_bytes"),
+                          "traffic_from": "committed profile (not a counter of this run)",
                           "algorithmic_bytes_per_evaluation": UNET_WEIGHT_BYTES,
+                          "latents_per_loop": lat_per_loop, "loops_in_flight": n_chains, "loops": loops,
                           "roof_us_per_evaluation": roof_eval_us,
                           "one_loop_alone_ms_per_evaluation": loop_alone_ms / T,
                           "one_loop_alone_frac": roof_eval_us * 1e-3 / (loop_alone_ms / T),
-                          "in_pipeline_ms_per_evaluation": loop_ms / max(loops, 1) / T,
-                          "loops_in_flight": len(chains)},
+                          "one_loop_alone_us_per_evaluation_and_latent": loop_alone_ms / T * 1e3 / lat_per_loop,
+                          "in_schedule_ms_per_evaluation": loop_ms / max(loops, 1) / T},
+        "time_share": ({"loops_alone_on_chip_ms": loop_phase_ms, "grids_ms": elapsed * 1e3 - loop_phase_ms,
+                        "loops_frac": loop_phase_ms / (elapsed * 1e3)} if loop_phase_ms is not None else None),
         "breakdown_ms_per_step": {"reverse_loop_latency": loop_ms / max(loops, 1), "decoder_fwd": fwd_ms / a.steps,
                                   "decoder_fwd_bwd": grad_ms / a.steps,
-                                  "decoder_fwd_bwd_tflops": (n_grad * B * a.steps * 2 * FWD_FLOP) / (grad_ms * 1e-3) / 1e12 if grad_ms > 0 else 0.0},
+                                  "decoder_fwd_bwd_tflops": (grad_total * 2 * FWD_FLOP) / (grad_ms * 1e-3) / 1e12 if grad_ms > 0 else 0.0},
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     if w_trace is not None:
-        # shapes/s on the trace workload if the grids were the only stage (the loop overlaps it in the pipeline)
         per_shape_ms = w_trace["decoder_fwd_ms_per_shape"] + w_trace["decoder_fwd_bwd_ms_per_shape"]
-        w_trace["note"] = ("decoder kernels alone on all CUs, values discarded; with this occupancy a batch's grids take "
-                           f"{per_shape_ms * B:.0f} ms, so the step is bound by the reverse loops ({loop_alone_ms:.0f} ms alone)")
+        w_trace["note"] = ("decoder kernels alone on all CUs, values discarded; with this occupancy a step's grids take "
+                           f"{per_shape_ms * B:.0f} ms against {loop_alone_ms / max(alone_n, 1):.0f} ms of reverse loop per step (one wide loop alone)")
         out["w_trace"] = w_trace
-    if not a.no_e2:
+    if mesh_stats is not None:
+        out["e2"] = {"status": "timed", "value": shapes / elapsed, "unit": "shapes/s", **mesh_stats}
+    elif not a.no_e2:
         out["e2"] = e2_estimate(a, elapsed, shapes, world)
     if not a.no_cpu_baseline and world == 1:          # a stated baseline of the N=1 line only
-        out["cpu_baseline"] = cpu_baseline(T, B, n_fwd, n_grad)
+        out["cpu_baseline"] = cpu_baseline(T, B, n_fwd, n_grad, a.latent)
     print(json.dumps(out))
 
 

@@ -98,6 +98,14 @@ int surfd_unet_set_precision(surfd_unet *u, int mode);
  * pay the split's redundant operand staging for parallelism it cannot get.  Results for different budgets differ in
  * fp32 summation order only.  No reference counterpart. */
 int surfd_unet_set_cu_budget(surfd_unet *u, int cus);
+/* Work decomposition of the f16x2 conv kernel.  design_batch = 0 (default): latency form — a workgroup owns one
+ * 32-row tile of a layer's output and the K split follows the batch at hand: fastest for ONE narrow loop alone on
+ * the chip.  design_batch > 0: wide form for loops over tens of latents (reference: the `batch_size` of
+ * sample/generate_*.py is the only batching the reference has) — a workgroup stages its GroupNorm/SiLU operand once
+ * for FOUR row tiles, and the K split is fixed per layer for a batch of `design_batch`, so a latent's result is
+ * bit-identical whatever batch width it rides in (tests/test_gpu_unet.py).  Results of the two forms differ in fp32
+ * summation order only.  No reference counterpart. */
+int surfd_unet_set_wide(surfd_unet *u, int design_batch);
 /* host-sync: number of workgroups of the f16x2 conv kernel that had to clamp an operand to the fp16 range since the
  * last reset (0 = every evaluation so far was inside the range the mode is exact for) */
 int surfd_unet_saturation_count(surfd_unet *u, int reset, int64_t *count, surfd_stream s);
@@ -229,6 +237,11 @@ int surfd_grid_fill_dense(surfd_grid *g, surfd_decoder *d, int sample, float gra
                           float *udf, float *grads, surfd_stream s);
 /* host-sync: counters of the last fill on this handle */
 int surfd_grid_get_stats(surfd_grid *g, surfd_grid_stats *out, surfd_stream s);
+/* host-sync: running totals over every fused fill (surfd_grid_fill / _fill_batch / _fill_dense) on this handle since
+ * the last reset — decoder forward queries per level, forward+backward queries, number of fills.  The totals are kept
+ * on the device by the fills themselves, so a throughput run can account for every query of hundreds of different
+ * shapes without a host read-back per shape (the reference prints nothing of the kind; bench.py's roofline uses it). */
+int surfd_grid_get_totals(surfd_grid *g, surfd_grid_stats *out, int64_t *fills, int reset, surfd_stream s);
 
 /* Same algorithm with an arbitrary host callable (the reference's udf_func contract):
  * begin -> for each level { points -> [host evaluates] -> commit } -> grad_points ->
@@ -253,6 +266,25 @@ int surfd_mc_udf(const float *udf, const float *grads, int nz, int ny, int nx, i
  * level with PyMCubes).  classic != 0: the original 256-case triangle table (PyMCubes' algorithm); 0: Lewiner's
  * disambiguated cases.  Same result accessors as surfd_mc_udf. */
 int surfd_mc_iso(const float *volume, int nz, int ny, int nx, double level, int classic, int step, surfd_mc **out);
+/* Sparse hand-off (reference meshudf/meshudf.py:344-349 copies the whole grid and gradient volume to the
+ * host, _marching_cubes_lewiner_cy.pyx:1131,1157-1158 then looks only at cubes whose corners are all <= 1.74 voxel):
+ *   device: surfd_band_compact  — voxel index, value (clamped at 0 as meshudf.py:338), gradient of every voxel with
+ *           udf <= max_thr, in voxel order, into the handle's device buffers (stream-ordered, no host sync)
+ *   host:   surfd_band_fetch    — host-sync on `copy_stream` only: count, then the band, into pinned memory
+ *           surfd_mc_udf_band   — scatters the band into a host scratch volume that is "far" everywhere else, runs the
+ *           same mesher, takes the band out again: the mesh of surfd_mc_udf on the dense volumes, bit for bit, at a cost
+ *           proportional to the band. */
+typedef struct surfd_band surfd_band;
+typedef struct surfd_mc_scratch surfd_mc_scratch;
+int surfd_band_create(int N, int64_t capacity, surfd_band **out);
+void surfd_band_destroy(surfd_band *b);
+int surfd_band_compact(surfd_band *b, const float *udf, const float *grads, float max_thr, surfd_stream s);
+int surfd_band_fetch(surfd_band *b, surfd_stream copy_stream, int64_t *count, const int32_t **index, const float **packed);
+int surfd_mc_band_threshold(int n, float *max_thr);          /* float(1.74 * 2 / (n - 1)), as the mesher compares */
+int surfd_mc_scratch_create(int n, surfd_mc_scratch **out);  /* host: n^3 x (4 + 12 + 1) bytes, zero pages until touched */
+void surfd_mc_scratch_destroy(surfd_mc_scratch *sc);
+int surfd_mc_udf_band(surfd_mc_scratch *sc, const int32_t *index, const float *packed /* [count][4]: udf, gx, gy, gz */,
+                      int64_t count, int step, surfd_mc **out);
 int64_t surfd_mc_num_vertices(const surfd_mc *m);
 int64_t surfd_mc_num_faces(const surfd_mc *m);
 /* vertices[V,3] in (z,y,x) voxel units, faces[F,3] (winding of gradient_direction="descent"), normals[V,3] (unit),

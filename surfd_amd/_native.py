@@ -53,6 +53,7 @@ _SIGS = {
     "surfd_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "surfd_unet_set_precision": (C.c_int, [_P, C.c_int]),
     "surfd_unet_set_cu_budget": (C.c_int, [_P, C.c_int]),
+    "surfd_unet_set_wide": (C.c_int, [_P, C.c_int]),
     "surfd_unet_saturation_count": (C.c_int, [_P, C.c_int, c_i64p, _P]),
     "surfd_unet_debug_only_op": (C.c_int, [_P, C.c_int]),
     "surfd_unet_debug_run_module": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -80,6 +81,7 @@ _SIGS = {
     "surfd_grid_fill_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "surfd_grid_fill_dense": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P]),
     "surfd_grid_get_stats": (C.c_int, [_P, C.POINTER(GridStats), _P]),
+    "surfd_grid_get_totals": (C.c_int, [_P, C.POINTER(GridStats), c_i64p, C.c_int, _P]),
     "surfd_grid_begin": (C.c_int, [_P, _P, _P, _P]),
     "surfd_grid_level_points": (C.c_int, [_P, C.c_int, _P, C.c_int64, c_i64p, _P]),
     "surfd_grid_level_commit": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
@@ -87,6 +89,14 @@ _SIGS = {
     "surfd_grid_grad_commit": (C.c_int, [_P, _P, C.c_int64, _P]),
     "surfd_mc_udf": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "surfd_mc_iso": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),
+    "surfd_band_create": (C.c_int, [C.c_int, C.c_int64, C.POINTER(_P)]),
+    "surfd_band_destroy": (None, [_P]),
+    "surfd_band_compact": (C.c_int, [_P, _P, _P, C.c_float, _P]),
+    "surfd_band_fetch": (C.c_int, [_P, _P, c_i64p, C.POINTER(_P), C.POINTER(_P)]),
+    "surfd_mc_band_threshold": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    "surfd_mc_scratch_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "surfd_mc_scratch_destroy": (None, [_P]),
+    "surfd_mc_udf_band": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.POINTER(_P)]),
     "surfd_mc_num_vertices": (C.c_int64, [_P]),
     "surfd_mc_num_faces": (C.c_int64, [_P]),
     "surfd_mc_copy": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -20,6 +20,12 @@
 //    MFMAs of the current one.
 //  * blockIdx -> (tile, batch chunk, K slice) is XCD-aware: all batch chunks that stream the same weight slice
 //    run on one XCD (block b runs on XCD b % 8), so a slice leaves HBM once and is re-read from that XCD's L2.
+//  * two work decompositions of the same arithmetic.  Latency form (WT = false; one narrow loop alone on the chip):
+//    a workgroup owns ONE 32-row tile, its four waves split the K slice and meet in LDS.  Wide form (WT = true;
+//    surfd_unet_set_wide, loops over tens of latents): a workgroup owns FOUR row tiles, one per wave, each wave
+//    running the whole K slice against the one staged operand — the GroupNorm / SiLU / split staging, which is
+//    what a workgroup spends its life on, is done once for 128 output rows instead of once per 32, and the K
+//    split depends on the layer only, so a latent's result does not depend on the batch it rides in.
 #include "common.h"
 #include "unet_api.h"
 #include "unet_plan.h"
@@ -64,7 +70,8 @@ struct Conv2Args {
     int plane;             // halfs between the high and the low plane of the slab
     int off_ex, off_red;   // byte offsets of the GroupNorm exchange area / reduction scratch in LDS
     int ntiles, nby, KS;
-    unsigned magic_nby, magic_ks;   // ceil(2^32 / d): x / d == umulhi(x, magic) for x < 2^16
+    int nrt;               // row groups: ntiles (latency form) or ceil(ntiles / 4) (wide form)
+    unsigned magic_nby, magic_ks, magic_g;   // ceil(2^32 / d): x / d == umulhi(x, magic) for x < 2^16 (d = nby, KS, nrt * KS)
     float *part;           // split-K partial tiles [KS][nby][ntiles][part_stride]
     int part_stride;
     int *counters;         // [nby][ntiles], zero between launches
@@ -87,7 +94,7 @@ __device__ __forceinline__ void lds_bar() {
 
 // VEC: float4 registers a thread holds while staging its channel (8: operand rows of 4..32 positions,
 // nb * Lin <= 32; 16: 64 positions).  PREF: request the next K block's operand before the current MFMAs.
-template <int VEC, bool PREF>
+template <int VEC, bool PREF, bool WT = false>
 __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args A) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
@@ -114,25 +121,43 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     const long long cyc0_ = (long long)__builtin_readcyclecounter();
 #endif
     // ---- XCD-aware decode: group g = (tile, K slice); every batch chunk of a group on XCD g % 8 ----
-    int tile, by, kz;
+    int tile, by, kz, rg;
+    bool tile_ok = true;           // wide form: the last row group may have fewer than four tiles (wave-uniform)
     {
         const int bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int j = A.nby == 1 ? idx : (int)__umulhi((unsigned)idx, A.magic_nby);   // idx / nby (host-made reciprocal, idx < 2^16; 2^32 / 1 does not fit)
-        by = idx - j * A.nby;
-        const int g = xcd + 8 * j;
-        if (g >= A.ntiles * A.KS) return;
-        tile = A.KS == 1 ? g : (int)__umulhi((unsigned)g, A.magic_ks);              // g / KS
-        kz = g - tile * A.KS;
+        const int G = A.nrt * A.KS;
+        int g;
+        if (G < 8) {
+            // fewer groups than XCDs (the 224-channel layers in the wide form): pinning a group to one XCD would leave most
+            // of the chip idle — consecutive blocks (= consecutive XCDs) take consecutive groups, no padding blocks
+            by = G == 1 ? bid : (int)__umulhi((unsigned)bid, A.magic_g);             // bid / G
+            g = bid - by * G;
+        } else {
+            const int xcd = bid & 7, idx = bid >> 3;
+            const int j = A.nby == 1 ? idx : (int)__umulhi((unsigned)idx, A.magic_nby);   // idx / nby (host-made reciprocal, idx < 2^16; 2^32 / 1 does not fit)
+            by = idx - j * A.nby;
+            g = xcd + 8 * j;
+            if (g >= G) return;
+        }
+        rg = A.KS == 1 ? g : (int)__umulhi((unsigned)g, A.magic_ks);                // g / KS
+        kz = g - rg * A.KS;
+        tile = rg;
+        if constexpr (WT) {
+            tile = rg * 4 + wave;
+            tile_ok = tile < A.ntiles;
+            tile = min(tile, A.ntiles - 1);       // an idle wave streams the last tile's weights (valid addresses, same schedule) and discards the result
+        }
     }
     const int b0 = by * A.bchunk;
     const int nb = min(A.bchunk, A.B - b0);
     const int M = nb * A.Lout;
-    const int nct = (M + 31) >> 5;                    // 1 or 2 column tiles (host guarantees M <= 64)
-    const int log2kp = (nct == 1) ? 2 : 1;            // k-parts: 4 or 2 waves share a column tile
+    // latency form: 1 or 2 column tiles (host guarantees M <= 64), 4 or 2 waves share a column tile as k-parts;
+    // wide form: one column tile (M <= 32), every wave runs the whole K slice for its own row tile
+    const int nct = WT ? 1 : (M + 31) >> 5;
+    const int log2kp = WT ? 0 : (nct == 1) ? 2 : 1;
     const int KP = 1 << log2kp;
-    const int ct = (nct == 1) ? 0 : (wave & 1);
-    const int kpart = (nct == 1) ? wave : (wave >> 1);
+    const int ct = (WT || nct == 1) ? 0 : (wave & 1);
+    const int kpart = WT ? 0 : (nct == 1) ? wave : (wave >> 1);
     int colb, coll;
     {
         int m = ct * 32 + (lane & 31);
@@ -445,27 +470,30 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc_sm[r] + acc_hh[r];
-    lds_bar();
-    if (kpart > 0) {
-        float *dst = red + ((kpart - 1) * nct + ct) * 1024;
+    if constexpr (!WT) {
+        lds_bar();
+        if (kpart > 0) {
+            float *dst = red + ((kpart - 1) * nct + ct) * 1024;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
-    }
-    lds_bar();
-    if (kpart == 0) {
-        for (int kp = 1; kp < KP; ++kp) {
-            const float *srcp = red + ((kp - 1) * nct + ct) * 1024;
+            for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+        }
+        lds_bar();
+        if (kpart == 0) {
+            for (int kp = 1; kp < KP; ++kp) {
+                const float *srcp = red + ((kp - 1) * nct + ct) * 1024;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += srcp[r * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[r] += srcp[r * 64 + lane];
+            }
         }
     }
+    const bool owner = WT ? tile_ok : kpart == 0;      // this wave holds a finished tile of the workgroup's K slice
     C2_STAMP(7);
     // ---- cross-workgroup K reduction (hand-off recipe R1, cdna_hip_programming.md §6 G16): write-through
     //      partial tiles -> vmcnt(0) -> barrier -> relaxed ticket; the last arriver acquires and sums in slice order
     if (A.KS > 1) {
-        const size_t slot = (size_t)by * A.ntiles + tile;
+        const size_t slot = (size_t)by * A.nrt + rg;
         float *mine = A.part + (((size_t)kz * A.nby + by) * A.ntiles + tile) * A.part_stride;
-        if (kpart == 0) {
+        if (owner) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const f32x4 val = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
@@ -487,7 +515,7 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
         }
         __syncthreads();
         if (*flag == 0) return;
-        if (kpart == 0) {
+        if (owner) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             for (int z = 0; z < A.KS; ++z) {
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     }
     C2_STAMP(8);
     // ---- epilogue ---------------------------------------------------------------------------------------
-    if (kpart == 0) {
+    if (owner) {
         const int m = ct * 32 + (lane & 31);
         const bool mok = m < M;
         const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
@@ -685,6 +713,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         } else if (is_out) { ptr = io.ext_out; bs = io.ext_out_bs; }
         else { ptr = const_cast<float *>(io.ext_in); bs = io.ext_in_bs; }
     };
+    const bool wide = u->wide_batch > 0;
     int Lin0 = 0, max_lsl = 1, max_blkp = 16;
     for (int s = 0; s < c.nseg; ++s) {
         const SegPlan &sp = c.seg[s];
@@ -710,13 +739,17 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     }
     A.Lsl = max_lsl;
     const int VEC = Lin0 == 64 ? 16 : 8;
-    int nb = std::min({B, (VEC * 4) / Lin0, std::max(1, 64 / A.Lout), 8});
+    // wide form: one column tile per workgroup (M <= 32); layers whose single batch entry already spans two column
+    // tiles (64 positions) stay in the latency form
+    const bool wt = wide && A.Lout <= 32 && VEC == 8;
+    const int nb_cap = std::min({(VEC * 4) / Lin0, std::max(1, (wt ? 32 : 64) / A.Lout), 8});
+    int nb = std::min(B, nb_cap);
     // one fp16 plane of the slab has a fixed size (the kernel addresses the low plane with an immediate): 28 KB
     // (36 KB for 64-long rows), i.e. <= 74 KB of LDS per workgroup so that two of them share a CU
     const size_t plane_halfs = VEC == 16 ? 18432 : 14336;
     while (nb > 1 && (size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) --nb;
     if ((size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) return 1;
-    if (nb * A.Lout > 64) return 1;
+    if (nb * A.Lout > (wt ? 32 : 64)) return 1;
     A.bchunk = nb;
     A.cs = max_blkp + 8;
     A.plane = (int)plane_halfs;
@@ -750,10 +783,22 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     static const int ks_max = env_int("SURFD_CONV2_KSMAX", 16);
     static const int ks_min_base = env_int("SURFD_CONV2_NOSPLIT_ABOVE", 200);
     const int base = A.ntiles * A.nby;
+    A.nrt = wt ? ceil_div(A.ntiles, 4) : A.ntiles;
     int KS = 1;
-    if (base < ks_min_base && nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / base)});
     A.part_stride = 2 * 1024;
-    if ((size_t)KS * base * A.part_stride > u->part_floats || base > 8192) KS = 1;
+    if (wide) {
+        // the K split is a function of the LAYER and of the handle's design batch only — never of B — so that a latent's
+        // result does not depend on the width of the batch it rides in
+        int nbd = std::min(u->wide_batch, nb_cap);
+        while (nbd > 1 && (size_t)nbd * A.Lsl * (max_blkp + 8) > plane_halfs) --nbd;
+        const int based = A.nrt * ceil_div(u->wide_batch, nbd);
+        if (nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / based)});
+        if ((size_t)KS * base * A.part_stride > u->part_floats || base > 8192)
+            SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv (wide form): batch of %d needs more split-K scratch than the handle holds", B);
+    } else {
+        if (base < ks_min_base && nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / base)});
+        if ((size_t)KS * base * A.part_stride > u->part_floats || base > 8192) KS = 1;
+    }
     A.KS = KS;
     A.part = u->part; A.counters = u->counters;
     A.sat = u->sat;
@@ -765,10 +810,15 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     }
     A.magic_nby = (unsigned)((0x100000000ULL + A.nby - 1) / A.nby);
     A.magic_ks = (unsigned)((0x100000000ULL + KS - 1) / KS);
-    const int G = A.ntiles * KS;
-    dim3 grid((unsigned)(8 * ceil_div(G, 8) * A.nby));
+    const int G = A.nrt * KS;
+    A.magic_g = (unsigned)((0x100000000ULL + G - 1) / G);
+    if ((long)G * A.nby >= 65536) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: %d x %d workgroups exceed the kernel's block decode", G, A.nby);
+    dim3 grid((unsigned)(G < 8 ? G * A.nby : 8 * ceil_div(G, 8) * A.nby));
     static const int pref = env_int("SURFD_CONV2_PREF", 0);      // operand prefetch across K blocks: measured 1.472 (on) vs 1.442 ms (off) per evaluation
-    if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
+    static const int wpref = env_int("SURFD_CONV2_WIDE_PREF", 0);
+    if (wt && wpref) hipLaunchKernelGGL((conv2_kernel<8, true, true>), grid, dim3(256), lds, st, A);
+    else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true>), grid, dim3(256), lds, st, A);
+    else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
     else if (pref) hipLaunchKernelGGL((conv2_kernel<8, true>), grid, dim3(256), lds, st, A);
     else hipLaunchKernelGGL((conv2_kernel<8, false>), grid, dim3(256), lds, st, A);
     LAUNCH_CHECK();
@@ -780,6 +830,8 @@ int conv2_set_attributes() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     return SURFD_OK;
 }
 

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "points.h"
 #include <string.h>
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 
 namespace surfd {
@@ -113,6 +114,16 @@ __global__ void grad_commit_kernel(const int *list, long n, const float *ng, flo
     }
 }
 
+// counters of the fill that just finished -> running totals of the handle (device side, no host sync)
+__global__ void accumulate_totals_kernel(const int *counters, unsigned long long *totals, int n_levels, long level0, long dense_n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (dense_n > 0) totals[n_levels - 1] += (unsigned long long)dense_n;
+    else
+        for (int l = 0; l < n_levels; ++l) totals[l] += l == 0 ? (unsigned long long)level0 : 7ull * (unsigned long long)counters[CTR_PARENT + l];
+    totals[SURFD_GRID_MAX_LEVELS] += (unsigned long long)counters[CTR_GRAD];
+    totals[SURFD_GRID_MAX_LEVELS + 1] += 1ull;
+}
+
 }  // namespace surfd
 
 using namespace surfd;
@@ -127,7 +138,8 @@ struct surfd_grid {
     float *cur_udf = nullptr, *cur_grads = nullptr;   // callback path
     bool dense_last = false;
     long dense_n = 0;
-    int *sort_out = nullptr; void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;   // callback path: deterministic list order
+    int *sort_out = nullptr; long sort_cap = 0; void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;   // callback path: deterministic list order (allocated on first use)
+    unsigned long long *totals = nullptr;            // [MAX_LEVELS] forward queries per level, [MAX_LEVELS] gradient queries, [MAX_LEVELS + 1] fills — since the last reset
     void *sel_tmp = nullptr; size_t sel_tmp_bytes = 0;                                // fused path: ordered compaction of the gradient voxels
 };
 
@@ -139,6 +151,13 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // (the host is synchronised at these points anyway).
 static int sort_list(surfd_grid *g, int *list, long n, hipStream_t st) {
     if (n <= 1) return SURFD_OK;
+    if (n > g->sort_cap) {                 // only the callback path sorts: sized to the lists it actually sees, not N^3 per handle
+        if (g->sort_out) HIP_TRY(hipFree(g->sort_out));
+        g->sort_out = nullptr;
+        const long cap = std::max<long>(n + n / 4, 1 << 16);
+        HIP_TRY(hipMalloc((void **)&g->sort_out, cap * sizeof(int)));
+        g->sort_cap = cap;
+    }
     size_t tmp_bytes = 0;
     const int end_bit = 3 * ilog2(g->N) + 1;
     HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, list, g->sort_out, (int)n, 0, end_bit, st));
@@ -181,7 +200,6 @@ static int grid_alloc(surfd_grid *g) {
     const long far_cap = nl >= 2 ? (long)g->levels[nl - 2] * g->levels[nl - 2] * g->levels[nl - 2] : 1;
     HIP_TRY(hipMalloc((void **)&g->far_list, far_cap * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->grad_list, N3 * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&g->sort_out, N3 * sizeof(int)));
     {
         hipcub::CountingInputIterator<int> idx(0);
         HIP_TRY(hipcub::DeviceSelect::If(nullptr, g->sel_tmp_bytes, idx, g->grad_list, g->counters, (int)N3, BelowThreshold{nullptr, 0.f}, nullptr));
@@ -189,6 +207,8 @@ static int grid_alloc(surfd_grid *g) {
     }
     HIP_TRY(hipMalloc((void **)&g->counters, CTR_TOTAL * sizeof(int)));
     HIP_TRY(hipMemset(g->counters, 0, CTR_TOTAL * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&g->totals, (SURFD_GRID_MAX_LEVELS + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(g->totals, 0, (SURFD_GRID_MAX_LEVELS + 2) * sizeof(unsigned long long)));
     g->allocated = true;
     return SURFD_OK;
 }
@@ -233,6 +253,13 @@ static int refine_level(surfd_grid *g, int level, float *udf, bool want_grads, h
     return SURFD_OK;
 }
 
+static int add_to_totals(surfd_grid *g, long dense_n, hipStream_t st) {
+    hipLaunchKernelGGL(accumulate_totals_kernel, dim3(1), dim3(64), 0, st, (const int *)g->counters, g->totals, g->n_levels,
+                       (long)g->levels[0] * g->levels[0] * g->levels[0], dense_n);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
 static int check_ready(const surfd_grid *g, const char *fn) {
     if (!g) SURFD_FAIL(SURFD_ERR_ARG, "%s: null handle", fn);
     if (!g->thresholds_set) SURFD_FAIL(SURFD_ERR_STATE, "%s: call surfd_grid_set_thresholds first", fn);
@@ -260,6 +287,7 @@ void surfd_grid_destroy(surfd_grid *g) {
     if (g->far_list) (void)hipFree(g->far_list);
     if (g->grad_list) (void)hipFree(g->grad_list);
     if (g->counters) (void)hipFree(g->counters);
+    if (g->totals) (void)hipFree(g->totals);
     if (g->sort_out) (void)hipFree(g->sort_out);
     if (g->sort_tmp) (void)hipFree(g->sort_tmp);
     if (g->sel_tmp) (void)hipFree(g->sel_tmp);
@@ -297,7 +325,7 @@ int surfd_grid_fill(surfd_grid *g, surfd_decoder *d, int sample, float *udf, flo
         if ((rc = decoder_launch(d, sample, io, true, -1, st))) return rc;
     }
     g->dense_last = false;
-    return SURFD_OK;
+    return add_to_totals(g, 0, st);
 }
 
 // The grids of `n` shapes (one handle each, all of one resolution) level by level TOGETHER: the decoder evaluates a level
@@ -346,6 +374,8 @@ int surfd_grid_fill_batch(surfd_grid *const *gs, int n, surfd_decoder *d, const 
         gb.io[gb.n++] = io;
     }
     if (gb.n && (rc = decoder_launch_batch(d, gb, true, -1, st))) return rc;
+    for (int i = 0; i < n; ++i)
+        if ((rc = add_to_totals(gs[i], 0, st))) return rc;
     return SURFD_OK;
 }
 
@@ -370,7 +400,7 @@ int surfd_grid_fill_dense(surfd_grid *g, surfd_decoder *d, int sample, float gra
     }
     g->dense_last = true;
     g->dense_n = N3;
-    return SURFD_OK;
+    return add_to_totals(g, N3, st);
 }
 
 int surfd_grid_get_stats(surfd_grid *g, surfd_grid_stats *out, surfd_stream s) {
@@ -390,6 +420,118 @@ int surfd_grid_get_stats(surfd_grid *g, surfd_grid_stats *out, surfd_stream s) {
         out->fwd_points[g->n_levels - 1] = g->dense_n;
     }
     out->grad_points = c[CTR_GRAD];
+    return SURFD_OK;
+}
+
+int surfd_grid_get_totals(surfd_grid *g, surfd_grid_stats *out, int64_t *fills, int reset, surfd_stream s) {
+    if (!g || !out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_get_totals: null argument");
+    if (!g->allocated) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_get_totals: nothing has been filled yet");
+    unsigned long long t[SURFD_GRID_MAX_LEVELS + 2];
+    HIP_TRY(hipMemcpyAsync(t, g->totals, sizeof(t), hipMemcpyDeviceToHost, as_stream(s)));
+    if (reset) HIP_TRY(hipMemsetAsync(g->totals, 0, sizeof(t), as_stream(s)));
+    HIP_TRY(hipStreamSynchronize(as_stream(s)));
+    memset(out, 0, sizeof(*out));
+    out->n_levels = g->n_levels;
+    for (int l = 0; l < g->n_levels; ++l) { out->levels[l] = g->levels[l]; out->fwd_points[l] = (int64_t)t[l]; }
+    out->grad_points = (int64_t)t[SURFD_GRID_MAX_LEVELS];
+    if (fills) *fills = (int64_t)t[SURFD_GRID_MAX_LEVELS + 1];
+    return SURFD_OK;
+}
+
+// ---- sparse hand-off to the host mesher -------------------------------------------------------------
+// The UDF marching cubes only ever looks at voxels whose value is at most max_thr = 1.74 voxel (mcubes.cpp): instead of
+// 16 N^3 bytes per shape (2.1 GB at 512^3) the device compacts that band — voxel index, value, gradient, in voxel order —
+// and the host copies count + band over a copy stream into pinned memory.
+}  // extern "C"
+
+namespace surfd {
+struct InBand {
+    const float *udf; float thr;
+    __device__ __forceinline__ bool operator()(const int &i) const { return !(udf[i] > thr); }
+};
+__global__ void band_gather_kernel(const int *idx, const int *count, long cap, const float *udf, const float *grads, float *packed) {
+    const long n = min((long)*count, cap);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long p = idx[e];
+        const float v = udf[p];
+        f32x4 o;
+        o[0] = v < 0.f ? 0.f : v;                        // get_mesh_from_udf clamps the grid at zero before meshing (meshudf.py:338)
+        o[1] = grads[3 * p]; o[2] = grads[3 * p + 1]; o[3] = grads[3 * p + 2];
+        *reinterpret_cast<f32x4 *>(packed + 4 * e) = o;
+    }
+}
+}  // namespace surfd
+
+struct surfd_band {
+    int N = 0; long cap = 0;
+    int *idx = nullptr, *count = nullptr; float *packed = nullptr;      // device
+    void *tmp = nullptr; size_t tmp_bytes = 0;
+    int *h_idx = nullptr, *h_count = nullptr; float *h_packed = nullptr;   // pinned host
+    hipEvent_t ready = nullptr;
+};
+
+extern "C" {
+
+int surfd_band_create(int N, int64_t capacity, surfd_band **out) {
+    if (!out || N < 2 || N > 1024 || capacity < 1 || capacity > (int64_t)N * N * N) SURFD_FAIL(SURFD_ERR_ARG, "surfd_band_create: bad argument");
+    auto *b = new surfd_band();
+    b->N = N; b->cap = capacity;
+    const int N3 = N * N * N;
+    // the ordered select writes every selected index: it needs room for the worst case, the gather and the copy only `capacity`
+    HIP_TRY(hipMalloc((void **)&b->idx, (size_t)N3 * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&b->count, sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&b->packed, (size_t)capacity * 4 * sizeof(float)));
+    hipcub::CountingInputIterator<int> it(0);
+    HIP_TRY(hipcub::DeviceSelect::If(nullptr, b->tmp_bytes, it, b->idx, b->count, N3, InBand{nullptr, 0.f}, nullptr));
+    HIP_TRY(hipMalloc(&b->tmp, b->tmp_bytes));
+    HIP_TRY(hipHostMalloc((void **)&b->h_idx, (size_t)capacity * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&b->h_packed, (size_t)capacity * 4 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&b->h_count, sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
+    *out = b;
+    return SURFD_OK;
+}
+
+void surfd_band_destroy(surfd_band *b) {
+    if (!b) return;
+    if (b->idx) (void)hipFree(b->idx);
+    if (b->count) (void)hipFree(b->count);
+    if (b->packed) (void)hipFree(b->packed);
+    if (b->tmp) (void)hipFree(b->tmp);
+    if (b->h_idx) (void)hipHostFree(b->h_idx);
+    if (b->h_packed) (void)hipHostFree(b->h_packed);
+    if (b->h_count) (void)hipHostFree(b->h_count);
+    if (b->ready) (void)hipEventDestroy(b->ready);
+    delete b;
+}
+
+int surfd_band_compact(surfd_band *b, const float *udf, const float *grads, float max_thr, surfd_stream s) {
+    if (!b || !udf || !grads) SURFD_FAIL(SURFD_ERR_ARG, "surfd_band_compact: null argument");
+    hipStream_t st = as_stream(s);
+    const int N3 = b->N * b->N * b->N;
+    hipcub::CountingInputIterator<int> it(0);
+    size_t bytes = b->tmp_bytes;
+    HIP_TRY(hipcub::DeviceSelect::If(b->tmp, bytes, it, b->idx, b->count, N3, InBand{udf, max_thr}, st));
+    hipLaunchKernelGGL(band_gather_kernel, dim3(1024), dim3(256), 0, st, (const int *)b->idx, (const int *)b->count, b->cap, udf, grads, b->packed);
+    LAUNCH_CHECK();
+    HIP_TRY(hipEventRecord(b->ready, st));
+    return SURFD_OK;
+}
+
+int surfd_band_fetch(surfd_band *b, surfd_stream copy_stream, int64_t *count, const int32_t **index, const float **packed) {
+    if (!b || !count || !index || !packed) SURFD_FAIL(SURFD_ERR_ARG, "surfd_band_fetch: null argument");
+    hipStream_t cs = as_stream(copy_stream);
+    HIP_TRY(hipStreamWaitEvent(cs, b->ready, 0));
+    HIP_TRY(hipMemcpyAsync(b->h_count, b->count, sizeof(int), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    const long n = *b->h_count;
+    if (n > b->cap) SURFD_FAIL(SURFD_ERR_STATE, "surfd_band_fetch: the band holds %ld voxels, the handle was created for %ld", n, b->cap);
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(b->h_idx, b->idx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(b->h_packed, b->packed, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipStreamSynchronize(cs));
+    }
+    *count = n; *index = b->h_idx; *packed = b->h_packed;
     return SURFD_OK;
 }
 

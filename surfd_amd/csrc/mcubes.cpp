@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <charconv>
 #include <cmath>
 #include <deque>
@@ -142,7 +143,8 @@ struct surfd_mc {
     std::vector<float> verts, normals, values;
     std::vector<int> faces;
 
-    ~surfd_mc() { free(state); }
+    bool owns_state = true;             // false: a scratch volume lent its own (surfd_mc_udf_band)
+    ~surfd_mc() { if (owns_state) free(state); }
 
     size_t vox(int z, int y, int x) const { return ((size_t)z * ny + y) * nx + x; }
 
@@ -630,28 +632,121 @@ extern "C" {
 int surfd_mc_iso(const float *volume, int nz, int ny, int nx, double level, int classic, int step, surfd_mc **out) {
     if (!volume || !out) { surfd::set_error("surfd_mc_iso: null argument"); return SURFD_ERR_ARG; }
     if (nx < 2 || ny < 2 || nz < 2 || step < 1) { surfd::set_error("surfd_mc_iso: volume must be at least 2x2x2 and step >= 1"); return SURFD_ERR_ARG; }
-    std::unique_ptr<surfd_mc> m(new surfd_mc());
-    m->nx = nx; m->ny = ny; m->nz = nz; m->st = step; m->im = volume;
-    m->cache.reset(new EdgeCache((size_t)nx * ny * nz));
-    m->run_iso(level, classic != 0);
-    m->im = nullptr;
-    *out = m.release();
+    // the scan always visits cube 0, whose far corners sit `step` voxels away
+    if (step > std::min(nx, std::min(ny, nz)) - 1) { surfd::set_error("surfd_mc_iso: step %d does not fit a %dx%dx%d volume", step, nz, ny, nx); return SURFD_ERR_ARG; }
+    try {
+        std::unique_ptr<surfd_mc> m(new surfd_mc());
+        m->nx = nx; m->ny = ny; m->nz = nz; m->st = step; m->im = volume;
+        m->cache.reset(new EdgeCache((size_t)nx * ny * nz));
+        m->run_iso(level, classic != 0);
+        m->im = nullptr;
+        *out = m.release();
+    } catch (const std::exception &e) {          // std::bad_alloc from the mesh vectors must not cross the C boundary
+        surfd::set_error("surfd_mc_iso: %s", e.what());
+        return SURFD_ERR_STATE;
+    }
     return SURFD_OK;
 }
 
 int surfd_mc_udf(const float *udf, const float *grads, int nz, int ny, int nx, int step, surfd_mc **out) {
     if (!udf || !grads || !out) { surfd::set_error("surfd_mc_udf: null argument"); return SURFD_ERR_ARG; }
     if (nx < 2 || ny < 2 || nz < 2 || step < 1) { surfd::set_error("surfd_mc_udf: volume must be at least 2x2x2 and step >= 1"); return SURFD_ERR_ARG; }
-    std::unique_ptr<surfd_mc> m(new surfd_mc());
-    m->nx = nx; m->ny = ny; m->nz = nz; m->st = step; m->im = udf; m->gr = grads;
-    const size_t n = (size_t)nx * ny * nz;
-    m->state = (unsigned char *)calloc(n, 1);
-    if (!m->state) { surfd::set_error("surfd_mc_udf: out of memory (%zu voxels)", n); return SURFD_ERR_STATE; }
-    m->cache.reset(new EdgeCache(n));
-    m->run();
-    m->im = m->gr = nullptr;
-    *out = m.release();
+    if (step > std::min(nx, std::min(ny, nz)) - 1) { surfd::set_error("surfd_mc_udf: step %d does not fit a %dx%dx%d volume", step, nz, ny, nx); return SURFD_ERR_ARG; }
+    try {
+        std::unique_ptr<surfd_mc> m(new surfd_mc());
+        m->nx = nx; m->ny = ny; m->nz = nz; m->st = step; m->im = udf; m->gr = grads;
+        const size_t n = (size_t)nx * ny * nz;
+        m->state = (unsigned char *)calloc(n, 1);
+        if (!m->state) { surfd::set_error("surfd_mc_udf: out of memory (%zu voxels)", n); return SURFD_ERR_STATE; }
+        m->cache.reset(new EdgeCache(n));
+        m->run();
+        m->im = m->gr = nullptr;
+        *out = m.release();
+    } catch (const std::exception &e) {
+        surfd::set_error("surfd_mc_udf: %s", e.what());
+        return SURFD_ERR_STATE;
+    }
     return SURFD_OK;
+}
+
+// ---- sparse hand-off: the mesher on the near-surface band only -------------------------------------------------------
+// marching_cubes_udf looks at a voxel only (a) to reject a cube — own corner or any corner above max_thr = 1.74 voxel
+// (pyx:1131,1157-1158) — or (b) as a corner / voting neighbour of a cube that passed, i.e. at voxels whose value is at
+// most max_thr.  A volume in which every voxel ABOVE max_thr is replaced by any other value above max_thr (and its
+// gradient by anything) therefore gives the same mesh, bit for bit.  The scratch below is such a volume kept on the
+// host between shapes: all "far" with zero gradients; a shape's band (voxel index, value, gradient — what the device
+// compacts and copies instead of 16 N^3 bytes) is scattered in, meshed by the unchanged run(), and taken out again, so
+// the cost per shape is proportional to the band.
+struct surfd_mc_scratch {
+    int n = 0;
+    float far_value = 0.f;
+    float *udf = nullptr, *grads = nullptr;
+    unsigned char *state = nullptr;
+    ~surfd_mc_scratch() { free(udf); free(grads); free(state); }
+};
+
+int surfd_mc_scratch_create(int n, surfd_mc_scratch **out) {
+    if (!out || n < 2 || n > 2048) { surfd::set_error("surfd_mc_scratch_create: need 2 <= n <= 2048"); return SURFD_ERR_ARG; }
+    std::unique_ptr<surfd_mc_scratch> sc(new surfd_mc_scratch());
+    const size_t v = (size_t)n * n * n;
+    sc->n = n;
+    sc->far_value = 1.0f;                                        // any value above max_thr = 3.48 / (n - 1)
+    sc->udf = (float *)malloc(v * sizeof(float));
+    sc->grads = (float *)calloc(v * 3, sizeof(float));          // zero pages: materialised only where a band touches them
+    sc->state = (unsigned char *)calloc(v, 1);
+    if (!sc->udf || !sc->grads || !sc->state) { surfd::set_error("surfd_mc_scratch_create: out of memory (%zu voxels)", v); return SURFD_ERR_STATE; }
+    for (size_t i = 0; i < v; ++i) sc->udf[i] = sc->far_value;
+    *out = sc.release();
+    return SURFD_OK;
+}
+
+void surfd_mc_scratch_destroy(surfd_mc_scratch *sc) { delete sc; }
+
+int surfd_mc_band_threshold(int n, float *max_thr) {
+    if (n < 2 || !max_thr) { surfd::set_error("surfd_mc_band_threshold: bad argument"); return SURFD_ERR_ARG; }
+    const double voxel = 2.0 / (n - 1);
+    *max_thr = (float)(1.74 * voxel);                            // the very float run() compares with
+    return SURFD_OK;
+}
+
+int surfd_mc_udf_band(surfd_mc_scratch *sc, const int32_t *index, const float *packed, int64_t count, int step, surfd_mc **out) {
+    if (!sc || !out || count < 0 || (count > 0 && (!index || !packed))) { surfd::set_error("surfd_mc_udf_band: bad argument"); return SURFD_ERR_ARG; }
+    const int n = sc->n;
+    if (step < 1 || step > n - 1) { surfd::set_error("surfd_mc_udf_band: step %d does not fit a %d^3 volume", step, n); return SURFD_ERR_ARG; }
+    const size_t v = (size_t)n * n * n;
+    float max_thr;
+    surfd_mc_band_threshold(n, &max_thr);
+    for (int64_t i = 0; i < count; ++i) {
+        if (index[i] < 0 || (size_t)index[i] >= v) { surfd::set_error("surfd_mc_udf_band: voxel index %d outside the %d^3 volume", index[i], n); return SURFD_ERR_ARG; }
+        if (packed[4 * i] > max_thr) { surfd::set_error("surfd_mc_udf_band: entry %lld holds %g, above the band threshold %g", (long long)i, packed[4 * i], max_thr); return SURFD_ERR_ARG; }
+    }
+    for (int64_t i = 0; i < count; ++i) {
+        const size_t p = (size_t)index[i];
+        sc->udf[p] = packed[4 * i];
+        sc->grads[3 * p] = packed[4 * i + 1]; sc->grads[3 * p + 1] = packed[4 * i + 2]; sc->grads[3 * p + 2] = packed[4 * i + 3];
+    }
+    int rc = SURFD_OK;
+    try {
+        std::unique_ptr<surfd_mc> m(new surfd_mc());
+        m->nx = n; m->ny = n; m->nz = n; m->st = step; m->im = sc->udf; m->gr = sc->grads;
+        m->state = sc->state; m->owns_state = false;
+        m->cache.reset(new EdgeCache(v));
+        m->run();
+        m->im = m->gr = nullptr;
+        m->state = nullptr;
+        *out = m.release();
+    } catch (const std::exception &e) {
+        surfd::set_error("surfd_mc_udf_band: %s", e.what());
+        rc = SURFD_ERR_STATE;
+    }
+    // state bytes are only ever written at corners of cubes that passed near_surface(): band voxels
+    for (int64_t i = 0; i < count; ++i) {
+        const size_t p = (size_t)index[i];
+        sc->udf[p] = sc->far_value;
+        sc->grads[3 * p] = sc->grads[3 * p + 1] = sc->grads[3 * p + 2] = 0.f;
+        sc->state[p] = 0;
+    }
+    return rc;
 }
 
 int64_t surfd_mc_num_vertices(const surfd_mc *m) { return m ? (int64_t)m->values.size() : 0; }

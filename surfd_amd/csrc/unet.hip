@@ -1238,12 +1238,17 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         return (long)bc * A.Lsl * (cc + 4) <= budget && (long)bc * cc / 4 <= 256 * rpt;                           // vectors for Linear layers
     };
     int bchunk = std::min(B, std::max(1, 512 / A.Lout));
+    // wide form (surfd_unet_set_wide): the Linear layers of the embedding path chunk their rows and their K axis as for
+    // eight rows whatever B is, so that an embedding row's summation order does not depend on the batch it is computed in
+    const bool fixed_rows = linear && u->wide_batch > 0;
+    const int chunk_rows = fixed_rows ? 8 : 0;
+    if (fixed_rows) bchunk = std::min(B, chunk_rows);
     while (bchunk > 1 && !fits(bchunk, need)) --bchunk;
     if (!fits(bchunk, need))
         SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv: operand does not fit LDS/registers (L=%d, C=%d)", L, c.seg[0].C);
     // more, smaller workgroups while the chip is under-filled (weights are then re-read through L2)
     const int ntiles = ceil_div(c.Cout, 32);
-    while (bchunk > 1 && ntiles * ceil_div(B, bchunk) < 128 && ((bchunk + 1) / 2) * A.Lout >= 32) bchunk = (bchunk + 1) / 2;
+    while (!fixed_rows && bchunk > 1 && ntiles * ceil_div(B, bchunk) < 128 && ((bchunk + 1) / 2) * A.Lout >= 32) bchunk = (bchunk + 1) / 2;
     A.bchunk = bchunk;
     // split K over workgroups when (channel tiles x batch chunks) cannot fill the chip: the heavy
     // low-resolution layers have 28 channel tiles and ONE batch chunk but stream 19 MB of weights
@@ -1263,7 +1268,7 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         const int Cp = ceil_div(sp.C, 8) * 8;
         int cc = std::min(ceil_div(Cp, unit) * unit, 4096);
         if (ks_target > 1) cc = std::min<long>(cc, std::max<long>(unit, ceil_div<long>(ceil_div<long>(work_per_slice, sp.taps), unit) * unit));
-        while (cc > unit && !fits(bchunk, cc)) cc -= unit;
+        while (cc > unit && !fits(fixed_rows ? chunk_rows : bchunk, cc)) cc -= unit;
         if (linear) { int p2 = 8; while (p2 * 2 <= cc) p2 *= 2; cc = p2; }   // power-of-two vectors per row (shift addressing)
         A.seg[s].cc = cc;
         nchunks += ceil_div(Cp, cc);
@@ -1491,6 +1496,12 @@ extern "C" int surfd_unet_set_precision(surfd_unet *u, int mode) {
 extern "C" int surfd_unet_set_cu_budget(surfd_unet *u, int cus) {
     if (!u || cus < 1 || cus > 256) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_cu_budget: need 1 <= cus <= 256");
     if (u->cu_budget != cus) { u->cu_budget = cus; u->ws_gen++; }      // captured loop graphs hold the old launch shapes
+    return SURFD_OK;
+}
+
+extern "C" int surfd_unet_set_wide(surfd_unet *u, int design_batch) {
+    if (!u || design_batch < 0 || design_batch > 4096) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_set_wide: need 0 <= design_batch <= 4096");
+    if (u->wide_batch != design_batch) { u->wide_batch = design_batch; u->ws_gen++; }      // captured loop graphs hold the old launch shapes
     return SURFD_OK;
 }
 

@@ -80,6 +80,7 @@ struct surfd_unet {
     _Float16 *whf = nullptr; size_t whf_halfs = 0;     // split-fp16 weight planes, fragment-major for the 32x32x16 MFMA
     float *wsc = nullptr; int n_sc = 0;                // per-layer power-of-two weight scale
     unsigned *sat = nullptr;                           // device counter: workgroups that clamped an operand to the fp16 range
+    int wide_batch = 0;                                // > 0: wide form of the f16x2 conv kernel, K split designed for this batch (surfd_unet_set_wide)
     int cu_budget = 256;                               // CUs this context's launches can count on (split-K sizing)
     int precision = 1;                                 // denoiser conv arithmetic: 1 = f16x2 (default), 0 = exact fp32 MFMA
     int dbg_only = -1;                                 // >= 0: only this conv op runs on the f16x2 kernel (surfd_unet_debug_only_op)

@@ -147,3 +147,160 @@ def bench_e2(resolution: int, e1_shapes_per_s: float, threads: int = 8) -> dict:
             "value": min(e1_shapes_per_s, par_rate), "unit": "shapes/s",
             "note": "host stage (pageable D2H + native marching cubes, one shape per core) overlapped with the GPU work of later "
                     "batches; reference marching cubes: 10.6 s per shape at 512^3 on one core (BASELINE.md)"}
+
+
+# ---- sparse hand-off: the mesher on the near-surface band only (csrc/mcubes.cpp: surfd_mc_udf_band) -------------------------
+def band_threshold(n: int) -> float:
+    """float32(1.74 * 2 / (n - 1)): the largest corner value a cube may have for the mesher to look at it
+    (_marching_cubes_lewiner_cy.pyx:1131,1157-1158), exactly as the library compares."""
+    t = C.c_float()
+    N.check(N.lib().surfd_mc_band_threshold(int(n), C.byref(t)))
+    return float(t.value)
+
+
+class McScratch:
+    """Host scratch volume of one meshing thread (n^3 voxels: value, gradient, state byte; pages appear where bands touch
+    them): surfd_mc_udf_band scatters a shape's band in, meshes, takes it out again."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+        h = C.c_void_p()
+        N.check(N.lib().surfd_mc_scratch_create(self.n, C.byref(h)))
+        self._h = h
+
+    def mesh(self, index, packed, count: int, step_size: int = 1):
+        """index: int32 voxel indices (pointer or array), packed: [count, 4] float32 (udf, gx, gy, gz) ->
+        (vertices, faces, normals, values) exactly as udf_mc_lewiner(...) with spacing 1 on the dense volumes."""
+        L = N.lib()
+        if isinstance(index, np.ndarray):
+            index = np.ascontiguousarray(index, np.int32)
+            packed = np.ascontiguousarray(packed, np.float32)
+            ip, pp = index.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)
+        else:
+            ip, pp = index, packed
+        h = C.c_void_p()
+        N.check(L.surfd_mc_udf_band(self._h, ip, pp, int(count), int(step_size), C.byref(h)))
+        try:
+            nv, nf = L.surfd_mc_num_vertices(h), L.surfd_mc_num_faces(h)
+            verts, normals = np.empty((nv, 3), np.float32), np.empty((nv, 3), np.float32)
+            values, faces = np.empty((nv,), np.float32), np.empty((nf, 3), np.int32)
+            N.check(L.surfd_mc_copy(h, verts.ctypes.data_as(C.c_void_p), faces.ctypes.data_as(C.c_void_p),
+                                    normals.ctypes.data_as(C.c_void_p), values.ctypes.data_as(C.c_void_p)))
+        finally:
+            L.surfd_mc_destroy(h)
+        return verts, faces, normals, values
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                N.lib().surfd_mc_scratch_destroy(self._h)
+        except Exception:
+            pass
+
+
+def band_of(volume: np.ndarray, grads: np.ndarray):
+    """numpy restatement of the device compaction (surfd_band_compact): (index int32 [n], packed float32 [n, 4]) of the voxels
+    with udf <= band_threshold, in voxel order."""
+    v = np.ascontiguousarray(volume, np.float32).reshape(-1)
+    idx = np.nonzero(~(v > np.float32(band_threshold(volume.shape[0]))))[0].astype(np.int32)
+    packed = np.empty((len(idx), 4), np.float32)
+    packed[:, 0] = np.maximum(v[idx], 0)
+    packed[:, 1:] = np.ascontiguousarray(grads, np.float32).reshape(-1, 3)[idx]
+    return idx, packed
+
+
+class BandMesher:
+    """End point E2 executed: for every finished grid the device compacts the near-surface band
+    (`submit`, stream-ordered on the caller's stream — no host sync), a pool of host threads fetches it over their own copy
+    streams into pinned memory and runs the native UDF marching cubes on it, while the GPU goes on with the next shapes.
+    `slots` band handles bound how far the GPU may run ahead of the mesher (submit blocks when all are in flight); `drain`
+    returns when every submitted shape is meshed.  Meshes are what udf_mc_lewiner gives on the dense grids, bit for bit
+    (tests/test_gpu_decoder_grid.py).  keep=True keeps (tag, vertices, faces) in .meshes, else only counts."""
+
+    def __init__(self, n: int, threads: int = 8, slots: int = 16, capacity: int = 1 << 21, keep: bool = False):
+        import queue
+        import threading
+
+        import torch
+        self.n, self.keep = int(n), keep
+        self.max_thr = band_threshold(n)
+        L = N.lib()
+        self._free, self._work = queue.Queue(), queue.Queue()
+        self._handles = []
+        for _ in range(slots):
+            h = C.c_void_p()
+            N.check(L.surfd_band_create(self.n, int(capacity), C.byref(h)))
+            self._handles.append(h)
+            self._free.put(h)
+        self.meshes, self.errors = [], []
+        self._lock = threading.Lock()
+        self.reset_stats()
+        self._threads_n = max(1, int(threads))
+        dev = torch.cuda.current_device()
+
+        def worker():
+            torch.cuda.set_device(dev)
+            scratch = McScratch(self.n)
+            copy_stream = torch.cuda.Stream()
+            while True:
+                item = self._work.get()
+                if item is None:
+                    self._work.task_done()
+                    return
+                h, tag = item
+                try:
+                    t0 = time.perf_counter()
+                    cnt, ip, pp = C.c_int64(), C.c_void_p(), C.c_void_p()
+                    N.check(L.surfd_band_fetch(h, C.c_void_p(copy_stream.cuda_stream), C.byref(cnt), C.byref(ip), C.byref(pp)))
+                    t1 = time.perf_counter()
+                    v, f, _, _ = scratch.mesh(ip, pp, cnt.value)
+                    t2 = time.perf_counter()
+                    with self._lock:
+                        self._st["shapes"] += 1; self._st["band_voxels"] += cnt.value
+                        self._st["wait_and_copy_s"] += t1 - t0; self._st["mesh_s"] += t2 - t1
+                        self._st["vertices"] += len(v); self._st["faces"] += len(f)
+                        if self.keep:
+                            self.meshes.append((tag, v, f))
+                except BaseException as e:
+                    self.errors.append(e)
+                finally:
+                    self._free.put(h)
+                    self._work.task_done()
+
+        import time
+        self._threads = [threading.Thread(target=worker, daemon=True) for _ in range(self._threads_n)]
+        for t in self._threads:
+            t.start()
+
+    def reset_stats(self):
+        self._st = {"shapes": 0, "band_voxels": 0, "wait_and_copy_s": 0.0, "mesh_s": 0.0, "vertices": 0, "faces": 0}
+
+    def submit(self, udf, grads, tag=None) -> None:
+        import torch
+        h = self._free.get()                                   # back-pressure: at most `slots` shapes between GPU and mesher
+        N.check(N.lib().surfd_band_compact(h, N.ptr(udf), N.ptr(grads), C.c_float(self.max_thr), N.stream()))
+        self._work.put((h, tag))
+
+    def drain(self) -> None:
+        self._work.join()
+        if self.errors:
+            raise self.errors[0]
+
+    def stats(self) -> dict:
+        s = dict(self._st)
+        n = max(1, s["shapes"])
+        return {"threads": self._threads_n, "slots": len(self._handles), "meshed_shapes": s["shapes"],
+                "band_voxels_per_shape": s["band_voxels"] / n, "d2h_bytes_per_shape": 20.0 * s["band_voxels"] / n + 4,
+                "dense_d2h_bytes_per_shape": 16.0 * self.n ** 3,
+                "mesh_s_per_shape_one_thread": s["mesh_s"] / n, "wait_and_copy_s_per_shape": s["wait_and_copy_s"] / n,
+                "vertices_per_shape": s["vertices"] / n, "faces_per_shape": s["faces"] / n}
+
+    def close(self) -> None:
+        for _ in self._threads:
+            self._work.put(None)
+        for t in self._threads:
+            t.join()
+        self._threads = []
+        for h in self._handles:
+            N.lib().surfd_band_destroy(h)
+        self._handles = []

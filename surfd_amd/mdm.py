@@ -117,6 +117,14 @@ class MDM(nn.Module):
         L, h = self._native()
         N.check(L.surfd_unet_set_cu_budget(h, int(cus)))
 
+    def set_wide(self, design_batch: int) -> None:
+        """Work decomposition of the f16x2 conv kernel: 0 = latency form (one narrow loop alone on the chip, the
+        default), n > 0 = wide form designed for loops over about n latents — the operand staging is shared by four
+        row tiles and the K split no longer depends on the batch, so a latent's result is bit-identical whatever
+        batch it rides in.  Applies to this execution context (replicas have their own setting)."""
+        L, h = self._native()
+        N.check(L.surfd_unet_set_wide(h, int(design_batch)))
+
     def saturation_count(self, reset: bool = True) -> int:
         """Workgroups of the f16x2 conv kernel that clamped an operand to +-65504 since the last reset; a non-zero
         value means this checkpoint leaves the range the mode is exact for -> use set_precision('fp32')."""

@@ -291,24 +291,52 @@ def keep_components_with_at_least(vertices: np.ndarray, faces: np.ndarray, min_f
     return np.asarray(vertices, dtype=np.float64)[used], remap[kept]
 
 
-def laplacian_smooth(vertices: np.ndarray, faces: np.ndarray, steps: int = 3) -> np.ndarray:
-    """Umbrella (uniform-weight) Laplacian smoothing of every vertex, `steps` Jacobi sweeps: each vertex moves to the
-    mean of its edge neighbours.  Stands in for MeshLab's apply_coord_laplacian_smoothing (3 steps by default;
-    MeshLab's default weighting is cotangent — package absent here, parity unpinned)."""
+def laplacian_smooth(vertices: np.ndarray, faces: np.ndarray, steps: int = 3, cotangent: bool = True,
+                     boundary: bool = True) -> np.ndarray:
+    """MeshLab's apply_coord_laplacian_smoothing with its defaults (stepsmoothnum=3, boundary=True, cotangentweight=True;
+    sample/generate_uncond.py:116-118), restated from the algorithm VCGlib publishes (Smooth::VertexCoordLaplacian +
+    AccumulateLaplacianInfo): per sweep every vertex gathers  sum_j w_j p_j  and  cnt = sum_j w_j  over its edges — an
+    interior edge is visited once per adjacent face with w = cot(angle opposite the edge in that face) (w = 1 without
+    `cotangent`) — and moves to (p + sum) / (1 + cnt); vertices with cnt <= 0 stay.  With `boundary` a vertex on an open
+    border is averaged ONLY with its neighbours along the border polyline (uniform weights, itself counted once more:
+    (2 p + n1 + n2) / 4), so hems, sleeves and necklines of an open UDF garment slide along their curve instead of being
+    pulled into the surface; boundary=False treats every edge as interior.  pymeshlab is absent here: parity unpinned,
+    behaviour pinned by tests/test_meshproc_cpu.py (a flat open sheet keeps its border lines)."""
     vertices = np.array(vertices, dtype=np.float64, copy=True)
     faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
     if len(faces) == 0:
         return vertices
-    e, _ = edges_of_faces(faces)
-    und = np.unique(np.sort(e, axis=1), axis=0)
-    src = np.concatenate([und[:, 0], und[:, 1]])
-    dst = np.concatenate([und[:, 1], und[:, 0]])
-    deg = np.bincount(src, minlength=len(vertices)).astype(np.float64)
-    has = deg > 0
+    nv = len(vertices)
+    v0 = faces[:, [0, 1, 2]].reshape(-1)              # edge j of a face joins corner j and j + 1; corner j + 2 is opposite
+    v1 = faces[:, [1, 2, 0]].reshape(-1)
+    v2 = faces[:, [2, 0, 1]].reshape(-1)
+    is_border = np.zeros(len(v0), dtype=bool)
+    if boundary:
+        is_border[border_edge_rows(faces)] = True
+    inner = ~is_border
+    i0, i1, i2 = v0[inner], v1[inner], v2[inner]
+    b0, b1 = v0[is_border], v1[is_border]
     for _ in range(steps):
+        if cotangent:
+            a, b = vertices[i1] - vertices[i2], vertices[i0] - vertices[i2]
+            cross = np.linalg.norm(np.cross(a, b), axis=1)
+            dot = np.einsum("ij,ij->i", a, b)
+            w = np.where(cross > 0, dot / np.where(cross > 0, cross, 1.0), 0.0)      # cot of the opposite angle (tan(pi/2 - angle))
+        else:
+            w = np.ones(len(i0))
         acc = np.zeros_like(vertices)
-        np.add.at(acc, src, vertices[dst])
-        vertices[has] = acc[has] / deg[has, None]
+        cnt = np.zeros(nv)
+        np.add.at(acc, i0, vertices[i1] * w[:, None]); np.add.at(acc, i1, vertices[i0] * w[:, None])
+        np.add.at(cnt, i0, w); np.add.at(cnt, i1, w)
+        if len(b0):
+            on = np.zeros(nv, dtype=bool)
+            on[b0] = True; on[b1] = True
+            acc[on] = vertices[on]                          # border vertices: what the interior edges gathered is discarded
+            cnt[on] = 1.0
+            np.add.at(acc, b0, vertices[b1]); np.add.at(acc, b1, vertices[b0])
+            np.add.at(cnt, b0, 1.0); np.add.at(cnt, b1, 1.0)
+        move = cnt > 0
+        vertices[move] = (vertices[move] + acc[move]) / (cnt[move, None] + 1.0)
     return vertices
 
 

@@ -100,6 +100,15 @@ class GridFiller:
         return {"levels": list(st.levels[:st.n_levels]), "fwd_per_level": list(st.fwd_points[:st.n_levels]),
                 "grad": int(st.grad_points)}
 
+    def totals(self, reset: bool = True) -> Dict:
+        """Running totals of every fused fill on this filler since the last reset (kept on the device by the fills, one
+        host read here): forward queries per level, forward+backward queries, fills."""
+        L, h = self._native()
+        st, n = N.GridStats(), C.c_int64()
+        N.check(L.surfd_grid_get_totals(h, C.byref(st), C.byref(n), int(reset), N.stream()))
+        return {"levels": list(st.levels[:st.n_levels]), "fwd_per_level": list(st.fwd_points[:st.n_levels]),
+                "grad": int(st.grad_points), "fills": int(n.value)}
+
     def fill_grid(self, udf_func: Callable[[Tensor], Tensor], max_batch: int, with_grads: bool = True,
                   out: Optional[Tuple[Tensor, Optional[Tensor]]] = None, stats: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
         L, h = self._native()

@@ -219,3 +219,100 @@ class BatchPipeline:
             torch.cuda.synchronize()
             self.timeline = [{"batch": f, "loop_done_ms": t_begin.elapsed_time(ev), "grids_start_ms": t_begin.elapsed_time(e0),
                               "grids_done_ms": t_begin.elapsed_time(e1)} for f, ev, e0, e1 in marks]
+
+
+class PhasedPipeline:
+    """Time-sliced schedule over independent batches on ONE GPU: all reverse loops of a ROUND of batches first — as
+    `chains` wide loops at once (each over several batches' latents: the denoiser's weights are streamed once per
+    evaluation for all of them; conv kernel in its wide form, `MDM.set_wide`), the whole chip theirs — then the grids of
+    the round, the decoder's persistent workgroups on every CU.  Neither stage has to share CUs with the other: the
+    decoder (512 registers per lane, one workgroup per CU) cannot co-reside with anything, and a loop squeezed onto a
+    quarter of the chip pays for it in workgroup slots (measured, profiles/r03_loop_batch.md).  A shape's result does
+    not depend on the round or the loop it rode in (tests/test_gpu_unet.py).
+
+        pipe = PhasedPipeline(loop_fn, fill_fn, chains=2, max_loop_batches=8)
+        pipe.run(n_batches)
+
+    loop_fn(first_batch, n_batches, chain) -> latents of batches [first_batch, first_batch + n_batches), batch-major;
+                                              enqueues ONE reverse loop on the current stream with execution context `chain`
+    fill_fn(batch, latents_of_batch) -> None  enqueues that batch's grid evaluation on the current stream
+    """
+
+    def __init__(self, loop_fn, fill_fn, chains: int = 2, max_loop_batches: int = 8):
+        self.loop_fn, self.fill_fn = loop_fn, fill_fn
+        self.chains = max(1, int(chains))
+        self.max_loop_batches = max(1, int(max_loop_batches))
+        self.loop_streams = [torch.cuda.Stream() for _ in range(self.chains)]
+        self.record_timeline = False
+        self.timeline = []
+
+    def plan(self, n_batches: int):
+        """[(first_batch, [(chain, first, count), ...]), ...]: rounds of at most chains * max_loop_batches batches, the
+        batches of the job spread evenly over the rounds and a round's batches evenly over the chains."""
+        per_round = self.chains * self.max_loop_batches
+        n_rounds = max(1, -(-n_batches // per_round))
+        rounds = []
+        for r in range(n_rounds):
+            first, count = shard_range(n_batches, n_rounds, r)
+            q = min(self.chains, count)
+            parts = []
+            for c in range(q):
+                f, n = shard_range(count, q, c)
+                if n:
+                    parts.append((c, first + f, n))
+            rounds.append((first, parts))
+        return rounds
+
+    def run(self, n_batches: int) -> None:
+        import threading
+        if n_batches <= 0:
+            return
+        cur = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
+        t_begin = None
+        if self.record_timeline:
+            self.timeline = []
+            t_begin = torch.cuda.Event(enable_timing=True)
+            t_begin.record(cur)
+        marks = []
+        for first, parts in self.plan(n_batches):
+            results, errors = {}, []
+
+            def worker(c, f, n):
+                try:
+                    torch.cuda.set_device(dev)
+                    st = self.loop_streams[c]
+                    with torch.cuda.stream(st):
+                        st.wait_stream(cur)                 # the previous round's grids are done before this round's loops start
+                        x = self.loop_fn(f, n, c)
+                        x.record_stream(cur)
+                        ev = torch.cuda.Event(enable_timing=self.record_timeline)
+                        ev.record(st)
+                    results[c] = (f, n, x, ev)
+                except BaseException as e:                  # surfaced on the calling thread
+                    errors.append(e)
+
+            # one host thread per loop: a loop call blocks its caller while the device queue is full
+            threads = [threading.Thread(target=worker, args=p, daemon=True) for p in parts[1:]]
+            for t in threads:
+                t.start()
+            worker(*parts[0])
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            for c, _, _ in parts:
+                cur.wait_event(results[c][3])
+            for c, _, _ in parts:
+                f, n, x, ev = results[c]
+                per = x.shape[0] // n
+                for b in range(n):
+                    self.fill_fn(f + b, x[b * per:(b + 1) * per])
+            if self.record_timeline:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(cur)
+                marks.append((first, [results[c][3] for c, _, _ in parts], e1, sum(n for _, _, n in parts)))
+        if self.record_timeline:
+            torch.cuda.synchronize()
+            self.timeline = [{"first_batch": f, "batches": nb, "loops_done_ms": max(t_begin.elapsed_time(e) for e in evs),
+                              "grids_done_ms": t_begin.elapsed_time(e1)} for f, evs, e1, nb in marks]

@@ -110,14 +110,60 @@ def test_argument_contract():
     np.testing.assert_array_equal(v1, v2)
 
 
-def test_case_tables_are_lewiners():
-    """Shapes of the published tables and a few structural invariants (every fan entry is an edge 0..11 or the
-    interior vertex 12; the sign-pattern table is symmetric under complement up to the configuration)."""
+def test_case_tables_are_lewiners(golden):
+    """The case tables compiled into the library ARE the reference's: SHA-256 and shape of every table against the
+    hashes tools/make_golden.py took from /root/reference/meshudf/_marching_cubes_lewiner_luts.py (and of the three
+    edge-corner tables of _marching_cubes_lewiner.py:171-224) — holds on any host, also where oracle/_ref is driven
+    with the library's own tables.  Plus a few structural invariants."""
+    import hashlib
     t = mcubes.lut_tables()
+    g = golden("g13_lut_sha256")
+    names = sorted(k[:-7] for k in g.files if k.endswith("_sha256"))
+    assert sorted(t) == names and len(t) == 51
+    for name in names:
+        assert tuple(int(v) for v in g[name + "_shape"]) == t[name].shape, name
+        assert hashlib.sha256(np.ascontiguousarray(t[name], np.int8).tobytes()).hexdigest() == str(g[name + "_sha256"]), name
     assert t["CASES"].shape == (256, 2) and t["TILING13_3"].shape == (2, 12, 30) and t["SUBCONFIG13"].shape == (64,)
     assert t["CASES"][0, 0] == 0 and t["CASES"][255, 0] == 0
     for name, ar in t.items():
         if name.startswith("TILING"):
-            assert ar.min() >= 0 and ar.max() <= 12, name
-    assert all(t["CASES"][i, 0] == t["CASES"][255 - i, 0] or t["CASES"][i, 0] in (3, 6, 7, 10, 12, 13) or True for i in range(256))
-    assert len(t) == 51
+            assert ar.min() >= 0 and ar.max() <= 12, name      # every fan entry is an edge 0..11 or the interior vertex 12
+    # a sign pattern and its complement are the same Lewiner case
+    assert all(t["CASES"][i, 0] == t["CASES"][255 - i, 0] for i in range(256))
+
+
+@pytest.mark.parametrize("name,n", [("two_spheres", 48), ("open_sheet", 48), ("noisy_blob", 48), ("thin_shell", 64), ("noisy_blob", 96)])
+def test_band_mesher_equals_dense_mesher(name, n):
+    """f1's sparse hand-off, host half: the mesher fed ONLY the voxels with udf <= 1.74 voxel (index, value, gradient —
+    what the device compacts) gives the mesh of the dense volumes bit for bit, shape after shape on one scratch volume
+    (which must come back clean), also where the band's order is not the voxel order."""
+    udf, grads = mc_fields.FIELDS[name](n)
+    v0, f0, n0, val0 = mcubes.udf_mc_lewiner(udf, grads)
+    idx, packed = mcubes.band_of(udf, grads)
+    assert 0 < len(idx) <= udf.size
+    sc = mcubes.McScratch(n)
+    for rep in range(2):
+        order = np.arange(len(idx)) if rep == 0 else np.random.default_rng(0).permutation(len(idx))
+        v, f, nr, val = sc.mesh(idx[order], packed[order], len(idx))
+        np.testing.assert_array_equal(f, f0)
+        np.testing.assert_array_equal(v, v0.astype(np.float32))
+        np.testing.assert_array_equal(nr, n0)
+        np.testing.assert_array_equal(val, val0)
+    # an empty band: no surface, and a band entry above the threshold is refused
+    ev, ef, _, _ = sc.mesh(np.zeros(0, np.int32), np.zeros((0, 4), np.float32), 0)
+    assert len(ev) == 0 and len(ef) == 0
+    bad = packed.copy(); bad[0, 0] = 0.5
+    with pytest.raises(RuntimeError, match="above the band threshold"):
+        sc.mesh(idx, bad, len(idx))
+    v, f, _, _ = sc.mesh(idx, packed, len(idx))                  # the refused call left the scratch clean
+    np.testing.assert_array_equal(f, f0)
+
+
+def test_mesher_rejects_steps_that_do_not_fit():
+    """step > min(dim) - 1 would read past the volume."""
+    udf, grads = mc_fields.FIELDS["two_spheres"](48)
+    for vol, g, step in [(udf[:2, :2, :2], grads[:2, :2, :2], 2), (udf[:3, :3, :3], grads[:3, :3, :3], 3)]:
+        with pytest.raises((RuntimeError, ValueError)):
+            mcubes.udf_mc_lewiner(np.ascontiguousarray(vol), np.ascontiguousarray(g), step_size=step)
+    with pytest.raises((RuntimeError, ValueError)):
+        mcubes._run(np.ascontiguousarray(udf[:2, :2, :2]), None, 2, 0.01, True)

@@ -458,6 +458,36 @@ def g13_marching_cubes(R, with_512: bool):
     save("g13_marching_cubes", **out)
 
 
+def g13_lut_hashes(R):
+    """SHA-256 + shape of every case table of the reference's meshudf/_marching_cubes_lewiner_luts.py (base64 int8
+    blobs) and of the three edge-corner tables its driver builds (_marching_cubes_lewiner.py:171-224): pins the
+    numbers compiled into surfd_amd/csrc/mc_luts.h on ANY host, also where the reference tree is absent."""
+    import base64
+    import importlib.util
+    from oracle import build_ref
+    spec = importlib.util.spec_from_file_location("ref_luts", os.path.join("/root/reference", "meshudf", "_marching_cubes_lewiner_luts.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for n in build_ref.LUT_ORDER[3:]:
+        shape, text = getattr(mod, n)
+        ar = np.frombuffer(base64.decodebytes(text.encode()), dtype=np.int8).reshape(shape)
+        out[n + "_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(ar).tobytes()).hexdigest())
+        out[n + "_shape"] = np.array(ar.shape)
+    # the driver's edge -> corner-offset tables: the three module-level assignments, evaluated from the reference source
+    import ast
+    tree = ast.parse(open(os.path.join("/root/reference", "meshudf", "_marching_cubes_lewiner.py")).read())
+    ns = {}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "").startswith("EDGETORELATIVEPOS"):
+            ns[node.targets[0].id] = np.array(ast.literal_eval(node.value.args[0]), np.int8)
+    for ours, theirs in (("EDGESRELX", "EDGETORELATIVEPOSX"), ("EDGESRELY", "EDGETORELATIVEPOSY"), ("EDGESRELZ", "EDGETORELATIVEPOSZ")):
+        ar = np.ascontiguousarray(np.asarray(ns[theirs]), np.int8)
+        out[ours + "_sha256"] = np.array(hashlib.sha256(ar.tobytes()).hexdigest())
+        out[ours + "_shape"] = np.array(ar.shape)
+    save("g13_lut_sha256", **out)
+
+
 XATTN_CASES = [   # name, query_dim, context_dim (None: self), heads, dim_head, b, n, m, masked
     ("self_small", 64, None, 4, 32, 2, 48, 48, False),
     ("cross_ldm", 320, 512, 8, 64, 3, 32, 77, True),            # LDM's usual text-conditioning shape
@@ -506,7 +536,7 @@ def main():
     jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
             "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
             "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R),
-            "g13": lambda: g13_marching_cubes(R, a.mc512), "g14": lambda: g14_cross_attention(R)}
+            "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g14": lambda: g14_cross_attention(R)}
     only = [s for s in a.only.split(",") if s]
     for name, fn in jobs.items():
         if only and name not in only:
