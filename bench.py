@@ -251,6 +251,29 @@ def make_trace(N):
     return lists
 
 
+def thin_shell_grid(N):
+    """(udf [N,N,N], grads [N,N,N,3]) of the thin-shell field on the device, as GridFiller(N) fills them (analytic
+    -normalize(grad) where the reference would differentiate): the mesher's input in the W-trace end-to-end mode."""
+    from surfd_amd.meshudf import GridFiller
+
+    class Field:
+        def __call__(self, c):
+            return analytic_field_gpu(c)
+
+        def grads(self, c, max_batch):
+            out = torch.empty_like(c)
+            for lo in range(0, c.shape[0], 1 << 20):
+                p = c[lo:lo + (1 << 20)].detach().clone().requires_grad_(True)
+                with torch.enable_grad():
+                    (g,) = torch.autograd.grad(analytic_field_gpu(p).sum(), p)
+                out[lo:lo + (1 << 20)] = -torch.nn.functional.normalize(g, dim=1)
+            return out
+    u, g = GridFiller(N).fill_grid(Field(), 2 ** 30)
+    u = u.clamp_min(0).contiguous()
+    torch.cuda.synchronize()
+    return u, g.contiguous()
+
+
 def time_trace(dec, lat, lists, reps=2):
     """Decoder kernels on the trace (values discarded): ms per shape and algorithmic TFLOP/s, forward and fwd+bwd."""
     n_f = sum(c.shape[0] for k, c in lists if k == "fwd")
@@ -380,6 +403,9 @@ def main():
                                        noise_stream=noise, fused=True)
 
     mesher = None
+    trace_grid = None
+    if a.endpoint == "e2" and trace is not None:
+        trace_grid = thin_shell_grid(N)                  # the field whose query lists the trace is: what a trained model's grids look like
     if a.endpoint == "e2":
         from surfd_amd.mcubes import BandMesher
         threads = a.mesh_threads or max(1, min(8, (os.cpu_count() or 8) // world - n_chains))
@@ -391,6 +417,8 @@ def main():
             for k in range(B):
                 for kind, c in trace:
                     (dec.udf if kind == "fwd" else dec.udf_and_ngrad)(c, k)
+                if mesher is not None:                   # ... and the mesh of the same field (222 793 vertices): band compaction, D2H, host mesher
+                    mesher.submit(trace_grid[0], trace_grid[1], tag=(step, k))
             return
         if len(fillers) == B:
             # all shapes of the step level by level together: one persistent decoder launch per level (meshudf.fill_grids)
@@ -431,7 +459,7 @@ def main():
 
     run_steps(a.warmup)
     if pipe is not None:
-        pipe.record_timeline = a.timeline or world > 1
+        pipe.record_timeline = True                       # a few HIP events per round: time_share / per_rank come from them
     torch.cuda.synchronize()
     reset_totals()
     barrier(world)
@@ -599,6 +627,79 @@ def main():
         out["e2"] = e2_estimate(a, elapsed, shapes, world)
     if not a.no_cpu_baseline and world == 1:          # a stated baseline of the N=1 line only
         out["cpu_baseline"] = cpu_baseline(T, B, n_fwd, n_grad, a.latent)
+    print(json.dumps(out))
+
+
+def grid_shard_main(a, world, rank):
+    """--mode grid-shard (north star: "shard the per-sample 512^3 grid evaluation across the GPUs"): the reverse loop of a
+    step's B shapes is replicated (deterministic: every rank computes the same latents), then every refinement level of
+    every shape's grid is split over the ranks by index range of the level's point list (voxel order, the same on every
+    rank) — each rank runs the decoder kernel on its slice, ncclAllGather over xGMI returns the whole level to everybody
+    (surfd_amd.parallel.ShardedField over GridFiller's callback path: 4 B per point per level, 12 B per gradient point).
+    Strong scaling of one shape's latency; one host read of the level's length per level (the list lengths live on the
+    device) is the only synchronisation besides the collective."""
+    from surfd_amd import synth
+    from surfd_amd.cbndec import make_udf_func
+    from surfd_amd.meshudf import GridFiller
+    from surfd_amd.parallel import ShardedField
+    cfg = CONFIGS[a.config]
+    if cfg["cond_mode"] != "no_cond":
+        raise SystemExit("--mode grid-shard is wired for the unconditional configurations (c2, c3)")
+    model, diffusion, dec = build_models(cfg, a.latent, a.decoder_precision, a.unet_precision)
+    if a.diffusion_steps != 1000:
+        from surfd_amd.diffusion import create_gaussian_diffusion
+        diffusion = create_gaussian_diffusion(types.SimpleNamespace(noise_schedule="cosine", sigma_small=True), f"ddim{a.diffusion_steps}")
+    T, B, N = diffusion.num_timesteps, a.batch, a.resolution
+    n_steps_max = max(a.steps, a.warmup, 1)
+    noise_bank = [synth.synth_noise_batch(T, s * B, B, a.latent).cuda() for s in range(n_steps_max)]     # the same shapes on every rank
+    filler = GridFiller(N)
+    udf = torch.empty(N, N, N, device="cuda")
+    grads = torch.empty(N, N, N, 3, device="cuda")
+    fwd_pts = [0.0]
+
+    def one_step(s):
+        lat = diffusion.p_sample_loop(model, (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise_bank[s], fused=True)
+        dec.bind_latents(lat.reshape(B, a.latent))
+        for k in range(B):
+            filler.fill_grid(ShardedField(make_udf_func(dec, lat[k], sample=k)), 2 ** 22, out=(udf, grads), stats=True)
+            fwd_pts[0] += sum(filler.last_stats["fwd_per_level"])
+        return lat
+
+    for s in range(a.warmup):
+        one_step(s)
+    fwd_pts[0] = 0.0
+    barrier(world)
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        lat = one_step(s)
+    torch.cuda.synchronize()
+    local_ms = (time.perf_counter() - t0) * 1e3
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    per_rank = None
+    if world > 1:
+        import torch.distributed as dist
+        mine = torch.tensor([local_ms], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": float(v[0]) / a.steps} for r, v in enumerate(allr)]
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return
+    shapes = B * a.steps                       # the SAME shapes on every rank: total work is fixed as N grows
+    out = {"metric": "shapes/sec end-to-end (1000-step uncond, 512^3 UDF) at 1/2/4/8 GPU", "value": shapes / elapsed, "unit": "shapes/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32 (split-fp16 matrix products, fp32 accumulation)" if a.decoder_precision == "f16x2" else "f32",
+           "data": "synthetic (seeded random-init weights, seeded noise)", "rccl_ranks": world,
+           "config": {"workload": f"{cfg['name']}; grid-shard mode: reverse loop replicated, every level of every shape's {N}^3 grid split over {world} rank(s) "
+                                  "by index range, values returned by ncclAllGather (end point E1)", "mode": "grid-shard", "baseline_config": a.config,
+                      "shapes_per_step": B, "resolution": N, "diffusion_steps": T, "decoder_fwd_queries_per_shape": fwd_pts[0] / max(shapes, 1),
+                      "host_syncs_per_shape": len(filler.N_levels) + 1,
+                      "parallelism": f"grid-shard x{world}: all_gather of 4 B per point per level + 12 B per gradient point over xGMI"}}
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     print(json.dumps(out))
 
 
