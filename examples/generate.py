@@ -11,9 +11,12 @@ reference's sample/generate_{uncond,cat,text,image,sketch}.py
 What the reference scripts do around the hot path is kept: checkpoints in the reference layouts (a flat ``Unet.*`` dict;
 ``{"decoder": ...}``), latent 32 for uncond / cat / sketch and 64 for text / image, 1000 ancestral steps with
 ``clip_denoised=False``, classifier-free wrapper when ``--guidance_param != 1``, one OBJ per shape, small connected
-components removed afterwards (2500 faces; 5000 for --watertight).  What is NOT here: the CLIP towers (no weights
-offline, outside the hot path) — the 512-d conditioning vector is read from ``--embedding`` (a torch / numpy file of
-shape [512] or [num_samples, 512]) — and the image mask / crop preprocessing that feeds CLIP.
+components removed afterwards (uncond / cat / image / sketch: MeshLab-default Laplacian smoothing + components below 2500
+faces; --watertight: below 5000 faces; text without --watertight: the get_mesh_from_udf mesh as it is, generate_text.py:159-171).
+Conditioning: ``--embedding`` (a torch / numpy file of shape [512] or [num_samples, 512]) or, with ``--clip_path`` pointing at
+CLIP ViT-B/32 weights (none exist offline), the towers of surfd_amd.clip_towers on ``--prompt`` / ``--image_path`` +
+``--mask_path`` (mask / crop preprocessing: surfd_amd.preprocess) / ``--sketch_path``, evaluated ONCE before the loop.
+The same code runs behind ``python -m sample.generate_{uncond,cat,text,image,sketch}`` with the reference's flag names.
 ``--synthetic`` writes synthetic checkpoints (surfd_amd.synth) first: a smoke run without any trained weights.
 """
 from __future__ import annotations
@@ -59,7 +62,18 @@ def parse(argv=None):
     ap.add_argument("--respacing", default="", help="e.g. ddim50 for a quick run (the reference always runs 1000 steps)")
     ap.add_argument("--seed", type=int, default=10)
     ap.add_argument("--synthetic", action="store_true", help="create synthetic checkpoints under --output_dir and use them")
+    ap.add_argument("--clip_path", default=None, help="CLIP ViT-B/32 weights (state_dict / TorchScript archive) for --prompt / --image_path / --sketch_path")
+    ap.add_argument("--bpe_path", default=None, help="text mode with --clip_path: CLIP's bpe_simple_vocab_16e6.txt.gz")
+    ap.add_argument("--image_path", default=None)
+    ap.add_argument("--mask_path", default=None)
+    ap.add_argument("--sketch_path", default=None)
     return ap.parse_args(argv)
+
+
+def postprocess_open_mesh(mode: str) -> bool:
+    """MeshLab smoothing + small-component removal after get_mesh_from_udf: every reference driver except generate_text.py,
+    which writes the mesh as it comes (sample/generate_text.py:159-171)."""
+    return mode != "text"
 
 
 def load_embedding(path, count):
@@ -80,8 +94,45 @@ def synthetic_checkpoints(out_dir, cond_mode, latent):
     return model_path, ae_path
 
 
+def conditioning_vectors(a, count):
+    """[count, 512] conditioning of the text / image / sketch modes: a precomputed embedding file, the CLIP towers on the
+    reference scripts' raw inputs (needs --clip_path), or — smoke runs only — seeded synthetic vectors."""
+    if a.embedding:
+        return load_embedding(a.embedding, count)
+    raw = {"text": a.prompt, "image": a.image_path, "sketch": a.sketch_path}[a.mode]
+    if a.clip_path is None:
+        if raw is not None and not a.synthetic:
+            raise SystemExit(f"{a.mode} mode: turning {raw!r} into the 512-d condition needs CLIP ViT-B/32 weights (--clip_path; none are "
+                             "available offline) — or pass the embedding itself with --embedding")
+        return synth.synth_context(0, count)
+    from PIL import Image
+    from surfd_amd import preprocess
+    from surfd_amd.clip_towers import ClipTowers, SimpleTokenizer
+    towers = ClipTowers.from_file(a.clip_path).to("cuda")
+    if a.mode == "text":
+        tok = SimpleTokenizer(a.bpe_path)
+        emb = towers.encode_text(tok.tokenize([a.prompt] * count).cuda())                 # models/mdm.py:86-89, hoisted out of the loop
+    elif a.mode == "image":
+        img = np.array(Image.open(a.image_path).convert("RGB"))
+        mask = np.array(Image.open(a.mask_path).convert("1"))
+        clean, _ = preprocess.masked_crops(img, mask, r=0.7)                              # sample/generate_image.py:92-107
+        emb = towers.encode_image(preprocess.clip_image_tensor(clean, 224)[None].cuda()).expand(count, -1)
+    else:
+        sk = Image.open(a.sketch_path).convert("RGB")                                      # sample/generate_sketch.py:70-80 (_transform: centre crop)
+        w, h = sk.size
+        side = min(w, h, 224) if min(w, h) >= 224 else min(w, h)
+        sk = sk.crop(((w - 224) // 2, (h - 224) // 2, (w - 224) // 2 + 224, (h - 224) // 2 + 224))
+        t = torch.from_numpy(np.asarray(sk, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        t = (t - torch.tensor(preprocess.CLIP_MEAN).view(3, 1, 1)) / torch.tensor(preprocess.CLIP_STD).view(3, 1, 1)
+        emb = towers.encode_image(t[None].cuda()).expand(count, -1)
+    return emb.float().contiguous().cpu()
+
+
 def main(argv=None):
-    a = parse(argv)
+    return run(parse(argv))
+
+
+def run(a):
     cond_mode, latent, kind = MODES[a.mode]
     torch.manual_seed(a.seed)
     if a.synthetic:
@@ -100,8 +151,7 @@ def main(argv=None):
     if kind == "label":
         y["action_text"] = torch.full((a.num_samples,), a.category, dtype=torch.int64, device="cuda")
     elif kind == "embedding":
-        emb = load_embedding(a.embedding, a.num_samples).cuda() if a.embedding else synth.synth_context(0, a.num_samples).cuda()
-        y["context"] = emb
+        y["context"] = conditioning_vectors(a, a.num_samples).cuda()
     if a.guidance_param != 1:
         y["scale"] = torch.full((a.num_samples,), a.guidance_param, device="cuda")
 
@@ -120,8 +170,10 @@ def main(argv=None):
             verts, faces = meshproc.keep_components_with_at_least(verts, faces, 5000)
         else:
             v, t = get_mesh_from_udf(field, coords_range=(-1, 1), max_dist=0.1, N=a.resolution, max_batch=2 ** 16, differentiable=False)
-            verts = meshproc.laplacian_smooth(v.cpu().numpy(), t.cpu().numpy(), steps=3)
-            verts, faces = meshproc.keep_components_with_at_least(verts, t.cpu().numpy(), 2500)
+            verts, faces = v.cpu().numpy(), t.cpu().numpy()
+            if postprocess_open_mesh(a.mode):
+                verts = meshproc.laplacian_smooth(verts, faces, steps=3)
+                verts, faces = meshproc.keep_components_with_at_least(verts, faces, 2500)
         path = os.path.join(a.output_dir, f"{stem}_{k}.obj")
         meshproc.write_obj(path, verts, faces)
         written.append((path, len(verts), len(faces)))

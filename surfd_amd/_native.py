@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsurfd_hip.so")
+# SURFD_LIB: a differently built copy of the same library (A/B timing of kernel variants, tools/build_variants.py)
+LIB_PATH = os.environ.get("SURFD_LIB") or os.path.join(_HERE, "lib", "libsurfd_hip.so")
 GRID_MAX_LEVELS = 8
 
 c_i64p = C.POINTER(C.c_int64)

@@ -50,7 +50,11 @@ constexpr int VOFF_BFCP = 0;
 __host__ __device__ constexpr int voff_bfc(int k, int which) { return H * (1 + 2 * k + which); }
 constexpr int VOFF_WOUT = H * (1 + 2 * NB);
 constexpr int VOFF_BOUT = H * (2 + 2 * NB);
-constexpr int VEC_FLOATS = VOFF_BOUT + 4;
+// f16x2 kernels: the biases that would be added to the residual stream are folded into the shift of the next conditional
+// BN instead (a*(net + CB) + b = a*net + (a*CB + b)): CB[k] = b_fc_p + sum_{j<k} b_fc_1[j], built at finalize.  The
+// accumulators are then never touched by the vector ALU between the matrix products (no AGPR -> VGPR -> AGPR round trips).
+__host__ __device__ constexpr int voff_cb(int k) { return VOFF_BOUT + 4 + H * k; }
+constexpr int VEC_FLOATS = VOFF_BOUT + 4 + H * (NB + 1);
 
 // ---- "f16x2" arithmetic (default; surfd_decoder_set_precision / SURFD_DECODER_PRECISION) -----------------
 // Every fp32 operand is split into two fp16 terms, x = xh + xl with |x - xh - xl| <= 2^-22 |x|, and the
@@ -175,6 +179,23 @@ __device__ __forceinline__ void mfma_step_f16x2(const f16x8 (&a)[2][2], const f1
 // depend on activations), so the L2 latency at every layer boundary hides behind the epilogue.
 // The 8 weight loads and 4 activation-fragment LDS reads of a k-step are interleaved one per MFMA.
 struct WStages { f16x8 b[4][4][2]; };        // D = 4 stages x 4 channel tiles x 2 planes
+// Stages of the NEXT matrix that the tail of a GEMM requests (they stay live through the epilogue in between, the point
+// of highest register pressure: both accumulator sets, the epilogue's temporaries).  D - 1 = 3 keeps the pipeline full
+// across the boundary; 2 leaves 32 more registers to the epilogue and requests the third stage when the next GEMM
+// starts (its k-steps 0 and 1, 1536 matrix-pipe cycles, cover that load's latency).
+#ifndef SURFD_DEC_WS_AHEAD
+#define SURFD_DEC_WS_AHEAD 0
+#endif
+constexpr int WS_AHEAD = SURFD_DEC_WS_AHEAD;
+// where the left-out stages are requested: 1 = by the caller before the barrier in front of the GEMM, 0 = when the GEMM starts
+#ifndef SURFD_DEC_REQ_EARLY
+#define SURFD_DEC_REQ_EARLY 0
+#endif
+constexpr bool REQ_EARLY = SURFD_DEC_REQ_EARLY != 0;
+#ifndef SURFD_DEC_FWD_STAGED
+#define SURFD_DEC_FWD_STAGED 0
+#endif
+constexpr bool FWD_STAGED = SURFD_DEC_FWD_STAGED != 0;   // forward kernel's epilogue in the gradient kernel's four-pairs-per-stage form
 
 template <int KS>
 __device__ __forceinline__ void load_wstage(f16x8 (&dst)[4][2], const _Float16 *Whf, unsigned lofs, int ks) {
@@ -199,7 +220,21 @@ __device__ __forceinline__ void gemm_prefetch_f16x2(WStages &ws, const _Float16 
     unsigned lofs = (unsigned)lane * 16u;
     asm volatile("" : "+v"(lofs));
 #pragma unroll
-    for (int d = 0; d < 3; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
+    for (int d = 0; d < WS_AHEAD; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
+}
+
+// the stages of a matrix that the previous GEMM's tail left out: requested by the caller once its epilogue's stores are
+// issued, BEFORE the barrier in front of the GEMM (the barrier wait and the accumulator set-up then cover the latency)
+template <int KS>
+__device__ __forceinline__ void gemm_request_f16x2(WStages &ws, const _Float16 *Whf, int lane) {
+    if constexpr (WS_AHEAD < 3 && REQ_EARLY) {
+        __builtin_amdgcn_sched_barrier(0);          // not hoisted into the epilogue: that is where the registers are needed
+        unsigned lofs = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lofs));
+#pragma unroll
+        for (int d = WS_AHEAD; d < 3; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int KS, int KSN>
@@ -228,7 +263,7 @@ __device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *W
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int ks = ks0 + j;
-            if (decltype(last)::value && j >= 1) load_wstage<KSN>(ws.b[(j + D - 1) % D], Wnext, lofs, j - 1);
+            if (decltype(last)::value && j >= 1) { if (j - 1 < WS_AHEAD) load_wstage<KSN>(ws.b[(j + D - 1) % D], Wnext, lofs, j - 1); }
             else load_wstage<KS>(ws.b[(j + D - 1) % D], Whf, lofs, ks + D - 1);
             load_xg(x[(j + 1) & 1], goff, (decltype(last)::value && j == D - 1) ? j : j + 1);
             mfma_step_f16x2(x[j & 1], ws.b[j], acc);
@@ -242,6 +277,10 @@ __device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *W
         }
     };
     load_x(x[0], 0);
+    if constexpr (!REQ_EARLY) {
+#pragma unroll
+        for (int d = WS_AHEAD; d < D - 1; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
+    }
 #pragma unroll 1
     for (int ks0 = 0; ks0 < KS - D; ks0 += D) group(ks0, std::false_type{});
     group(KS - D, std::true_type{});
@@ -325,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                if constexpr (!GRAD) {
+                if constexpr (!GRAD && !FWD_STAGED) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float t0 = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]);
@@ -477,6 +516,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                 row[256 + i] = lo;
             }
         }
+        if constexpr (F16X2) gemm_request_f16x2<KS_E>(ws, whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, lane);
         TPHASE(0);
         TBAR();
         // ---- 3. fc_p -----------------------------------------------------------------------
@@ -494,14 +534,15 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
         for (int nt = 0; nt < 4; ++nt) {
             const std::conditional_t<F16X2, unsigned, int> c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
             nsa[nt] = scl(tab[c], winv); nsb[nt] = tab[H + c];
+            if constexpr (F16X2) nsb[nt] = __builtin_fmaf(tab[c], vecs[voff_cb(0) + c], nsb[nt]);      // fc_p's bias, folded
         }
         if constexpr (F16X2) gemm_2x4_f16x2<KS_E, KS_H>(X, whf + (size_t)(4 * wave_u) * KS_E * 2 * 512,
                                                       whf + hf_off_fc(0, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512, ws, net, lane);
         else gemm_2x4<KG_E>(E, ES, wpack + OFF_FCP + (size_t)(4 * wave) * KG_E * 256, net, lane);
-        {
+        if constexpr (!F16X2) {
             float bias[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bias[nt] = scl(vecs[VOFF_BFCP + (F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col)], wsc);
+            for (int nt = 0; nt < 4; ++nt) bias[nt] = vecs[VOFF_BFCP + 32 * (4 * wave + nt) + col];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -537,6 +578,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                         }
                 }
             }
+            if constexpr (F16X2) gemm_request_f16x2<KS_H>(ws, whf + hf_off_fc(k, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512, lane);
             TPHASE(2);
             TBAR();
             zero_acc(tmp);
@@ -579,6 +621,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                         }
                 }
             }
+            if constexpr (F16X2) gemm_request_f16x2<KS_H>(ws, whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512, lane);
             TPHASE(2);
             TBAR();
             // net += fc_1(X) + bias1   (residual accumulates straight into the MFMA C operand)
@@ -586,9 +629,10 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const std::conditional_t<F16X2, unsigned, int> c = F16X2 ? cb + 32 * nt : 32 * (4 * wave + nt) + col;
-                bias1[nt] = scl(vecs[voff_bfc(k, 1) + c], wsc);
+                bias1[nt] = F16X2 ? 0.f : vecs[voff_bfc(k, 1) + c];
                 nsa[nt] = scl(tab[(2 * k + 2) * 2 * H + c], winv);   // next block's first CBN (or the final one)
                 nsb[nt] = tab[(2 * k + 2) * 2 * H + H + c];
+                if constexpr (F16X2) nsb[nt] = __builtin_fmaf(tab[(2 * k + 2) * 2 * H + c], vecs[voff_cb(k + 1) + c], nsb[nt]);   // biases so far, folded
             }
             if constexpr (F16X2) {
                 if (k + 1 < NB) gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fc(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
@@ -599,7 +643,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                                                 whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, ws, net, lane);     // next tile's fc_p
             }
             else gemm_2x4<KG_H>(X, XS, wpack + off_fc(k, 1) + (size_t)(4 * wave) * KG_H * 256, net, lane);
-            {
+            if constexpr (!F16X2) {
                 float bias[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) bias[nt] = bias1[nt];
@@ -737,6 +781,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                     float f1[4];
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) f1[nt] = tab[(2 * k + 1) * 2 * H + cb + 32 * nt] * (winv * inv_s);
+                    gemm_request_f16x2<KS_H>(ws, whf + hf_off_fcT(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512, lane);
                     __syncthreads();
                     zero_acc(tmp);
                     gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fcT(k, 1) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
@@ -755,6 +800,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                     float f0[4];
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) f0[nt] = tab[(2 * k) * 2 * H + cb + 32 * nt] * (winv * inv_s);
+                    gemm_request_f16x2<KS_H>(ws, whf + hf_off_fcT(k, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512, lane);
                     __syncthreads();
                     zero_acc(tmp);
                     if (k > 0) gemm_2x4_f16x2<KS_H, KS_H>(X, whf + hf_off_fcT(k, 0) + (size_t)(4 * wave_u) * KS_H * 2 * 512,
@@ -926,6 +972,15 @@ __global__ void pack_f16x2_kernel(const float *wp, int KG, int KS, int permute, 
         const size_t base = ((size_t)(tile * KS + ks) * 2) * 512 + (size_t)lane * 8 + el;
         dst[base] = h; dst[base + 512] = l;
     }
+}
+
+// CB[k][c] = b_fc_p[c] + sum_{j<k} b_fc_1[j][c], k = 0..NB
+__global__ void cumbias_kernel(float *vecs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    float acc = vecs[VOFF_BFCP + c];
+    vecs[voff_cb(0) + c] = acc;
+    for (int k = 0; k < NB; ++k) { acc += vecs[voff_bfc(k, 1) + c]; vecs[voff_cb(k + 1) + c] = acc; }
 }
 
 struct CbnParams {
@@ -1165,6 +1220,8 @@ int surfd_decoder_finalize(surfd_decoder *d, surfd_stream s) {
     hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, st, d->wpack, SZ_FCP + (size_t)2 * NB * SZ_HH, maxbits);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1), 0, st, maxbits, d->vecs + VOFF_SC);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(cumbias_kernel, dim3(H / 256), dim3(256), 0, st, d->vecs);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(pack_f16x2_kernel, dim3(128), dim3(256), 0, st, d->wpack + OFF_FCP, KG_E, KS_E, 0, d->vecs + VOFF_SC, d->whf);
     LAUNCH_CHECK();

@@ -488,6 +488,44 @@ def g13_lut_hashes(R):
     save("g13_lut_sha256", **out)
 
 
+def g15_image_preprocess(R):
+    """f4: sample/generate_image.py:92-107's mask / crop preprocessing with the reference's OWN functions
+    (data_loaders/dataset.py:19-77; the module imports torchvision at the top, absent here, so the two function
+    definitions are evaluated from the reference source with numpy and PIL, which is all they use) on seeded images
+    whose masks touch every border case of the padding logic."""
+    import ast
+    from PIL import Image
+    src = open(os.path.join("/root/reference", "data_loaders", "dataset.py")).read()
+    tree = ast.parse(src)
+    ns = {"np": np, "Image": Image}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("mask2bbox", "crop_square"):
+            exec(compile(ast.Module([node], []), "dataset.py", "exec"), ns)
+    rng = np.random.default_rng(15)
+    cases = {"center": (300, 400, (120, 90, 260, 210)), "tall_left": (240, 320, (0, 10, 60, 230)), "wide_bottom": (200, 360, (40, 150, 359, 199)),
+             "corner": (180, 180, (120, 0, 179, 70)), "whole": (128, 160, (0, 0, 159, 127)), "thin": (256, 256, (100, 30, 103, 220))}
+    out = {}
+    for name, (h, w, (x0, y0, x1, y1)) in cases.items():
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        # smooth it a little so that the bicubic resize is not pure noise
+        img = (0.5 * img + 0.5 * np.roll(img, 3, axis=1)).astype(np.uint8)
+        mask = np.zeros((h, w), dtype=bool)
+        yy, xx = np.mgrid[0:h, 0:w]
+        mask[(yy >= y0) & (yy <= y1) & (xx >= x0) & (xx <= x1) & (((yy + xx) % 7) != 0)] = True
+        mask[y0, x0] = mask[y1, x1] = True
+        bbox = ns["mask2bbox"](mask)
+        r = 0.7
+        comp = img * mask[:, :, None] + (1 - mask[:, :, None]) * (r * 255 + (1 - r) * img)
+        clean = img * mask[:, :, None]
+        out[name + "__img"], out[name + "__mask"] = img, mask
+        out[name + "__bbox"] = np.array([int(v) for v in bbox])
+        for tag, arr in (("comp", comp), ("clean", clean)):
+            res = np.ascontiguousarray(np.array(ns["crop_square"](arr.astype(np.uint8), list(bbox))))
+            out[f"{name}__{tag}_sha256"] = np.array(hashlib.sha256(res.tobytes()).hexdigest())      # the whole 256 x 256 x 3 crop
+            out[f"{name}__{tag}_sub"] = res[::8, ::8].copy()                                          # every 8th pixel, for a readable failure
+    save("g15_image_preprocess", **out)
+
+
 XATTN_CASES = [   # name, query_dim, context_dim (None: self), heads, dim_head, b, n, m, masked
     ("self_small", 64, None, 4, 32, 2, 48, 48, False),
     ("cross_ldm", 320, 512, 8, 64, 3, 32, 77, True),            # LDM's usual text-conditioning shape
@@ -536,7 +574,7 @@ def main():
     jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
             "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
             "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R),
-            "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g14": lambda: g14_cross_attention(R)}
+            "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g15": lambda: g15_image_preprocess(R), "g14": lambda: g14_cross_attention(R)}
     only = [s for s in a.only.split(",") if s]
     for name, fn in jobs.items():
         if only and name not in only:
