@@ -192,6 +192,7 @@ constexpr int WS_AHEAD = SURFD_DEC_WS_AHEAD;
 #define SURFD_DEC_REQ_EARLY 0
 #endif
 constexpr bool REQ_EARLY = SURFD_DEC_REQ_EARLY != 0;
+constexpr int REQ_EARLY_UPTO = SURFD_DEC_REQ_EARLY == 2 ? WS_AHEAD + 1 : 3;      // 2: only the first left-out stage goes early, the rest at GEMM start
 #ifndef SURFD_DEC_FWD_STAGED
 #define SURFD_DEC_FWD_STAGED 0
 #endif
@@ -232,7 +233,7 @@ __device__ __forceinline__ void gemm_request_f16x2(WStages &ws, const _Float16 *
         unsigned lofs = (unsigned)lane * 16u;
         asm volatile("" : "+v"(lofs));
 #pragma unroll
-        for (int d = WS_AHEAD; d < 3; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
+        for (int d = WS_AHEAD; d < REQ_EARLY_UPTO; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -277,10 +278,8 @@ __device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *W
         }
     };
     load_x(x[0], 0);
-    if constexpr (!REQ_EARLY) {
 #pragma unroll
-        for (int d = WS_AHEAD; d < D - 1; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
-    }
+    for (int d = REQ_EARLY ? REQ_EARLY_UPTO : WS_AHEAD; d < D - 1; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
 #pragma unroll 1
     for (int ks0 = 0; ks0 < KS - D; ks0 += D) group(ks0, std::false_type{});
     group(KS - D, std::true_type{});

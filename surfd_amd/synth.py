@@ -114,3 +114,41 @@ def synth_context(first: int, count: int, dim: int = 512, seed: int = 77) -> tor
         g.manual_seed(seed * 1000003 + first + i)
         rows.append(torch.randn(dim, generator=g, dtype=torch.float32) * 0.3)
     return torch.stack(rows, 0)
+
+
+def synth_clip_state_dict(seed: int = 0, embed_dim: int = 512, image_resolution: int = 224, vision_layers: int = 12, vision_width: int = 768,
+                          vision_patch_size: int = 32, context_length: int = 77, vocab_size: int = 49408, transformer_width: int = 512,
+                          transformer_layers: int = 12) -> Dict[str, torch.Tensor]:
+    """Seeded stand-in for CLIP ViT-B/32 weights in OpenAI's checkpoint layout (no weights are available offline):
+    per-tensor seeded normals with the standard deviations CLIP initialises with, so that activations stay O(1)."""
+    sd: Dict[str, torch.Tensor] = {}
+
+    def put(key, shape, std, mean=0.0):
+        sd[key] = _normal(tuple(shape), std, "clip." + key, seed, mean=mean)
+
+    def blocks(prefix, width, layers):
+        attn_std, proj_std, fc_std = width ** -0.5, (width ** -0.5) * ((2 * layers) ** -0.5), (2 * width) ** -0.5
+        for i in range(layers):
+            p = f"{prefix}transformer.resblocks.{i}."
+            put(p + "attn.in_proj_weight", (3 * width, width), attn_std); put(p + "attn.in_proj_bias", (3 * width,), 0.01)
+            put(p + "attn.out_proj.weight", (width, width), proj_std); put(p + "attn.out_proj.bias", (width,), 0.01)
+            put(p + "ln_1.weight", (width,), 0.05, 1.0); put(p + "ln_1.bias", (width,), 0.05)
+            put(p + "ln_2.weight", (width,), 0.05, 1.0); put(p + "ln_2.bias", (width,), 0.05)
+            put(p + "mlp.c_fc.weight", (4 * width, width), fc_std); put(p + "mlp.c_fc.bias", (4 * width,), 0.01)
+            put(p + "mlp.c_proj.weight", (width, 4 * width), proj_std); put(p + "mlp.c_proj.bias", (width,), 0.01)
+
+    grid = image_resolution // vision_patch_size
+    put("visual.conv1.weight", (vision_width, 3, vision_patch_size, vision_patch_size), 0.02)
+    put("visual.class_embedding", (vision_width,), vision_width ** -0.5)
+    put("visual.positional_embedding", (grid * grid + 1, vision_width), vision_width ** -0.5)
+    put("visual.ln_pre.weight", (vision_width,), 0.05, 1.0); put("visual.ln_pre.bias", (vision_width,), 0.05)
+    blocks("visual.", vision_width, vision_layers)
+    put("visual.ln_post.weight", (vision_width,), 0.05, 1.0); put("visual.ln_post.bias", (vision_width,), 0.05)
+    put("visual.proj", (vision_width, embed_dim), vision_width ** -0.5)
+    put("token_embedding.weight", (vocab_size, transformer_width), 0.02)
+    put("positional_embedding", (context_length, transformer_width), 0.01)
+    blocks("", transformer_width, transformer_layers)
+    put("ln_final.weight", (transformer_width,), 0.05, 1.0); put("ln_final.bias", (transformer_width,), 0.05)
+    put("text_projection", (transformer_width, embed_dim), transformer_width ** -0.5)
+    sd["logit_scale"] = torch.tensor(2.6592)
+    return sd

@@ -59,3 +59,34 @@ def test_synthetic_checkpoints_have_the_reference_layouts(drv, tmp_path):
     ae = torch.load(ae_path, map_location="cpu")
     dec = CbnDecoder(63, 32, 512, 5)
     dec.load_state_dict(ae["decoder"], strict=True)
+
+
+def test_text_mode_writes_the_mesh_as_it_comes(drv):
+    """sample/generate_text.py:159-171 exports the get_mesh_from_udf mesh without MeshLab smoothing or component
+    removal; the four other drivers post-process."""
+    assert not drv.postprocess_open_mesh("text")
+    assert all(drv.postprocess_open_mesh(m) for m in ("uncond", "cat", "image", "sketch"))
+
+
+def test_sample_command_lines_take_the_reference_flags():
+    """python -m sample.generate_* (README.md:39-76): the reference's flag names and defaults (utils/parser_util.py:40-176),
+    including its quirk that the guidance scale is reset to 1 unless --cond_mask_prob is given (:19-20)."""
+    from sample import _common as sc
+    a = sc.generate_args(["--model_path", "pretrained_models/diffusion_uncond.pt", "--output_dir", "./outputs/uncond/", "--cond_mode", "no_cond",
+                          "--ae_dir", "pretrained_models/ae_deepfashion3d.pt", "--num_samples", "10", "--resolution", "512"])
+    assert (a.num_samples, a.resolution, a.cond_mode, a.seed, a.batch_size, a.guidance_param, a.noise_schedule, a.diffusion_steps) == \
+        (10, 512, "no_cond", 10, 64, 1, "cosine", 1000)
+    a = sc.generate_args(["--model_path", "m.pt", "--cond_mode", "text", "--ae_dir", "ae.pt", "--prompt", "a dining chair", "--watertight",
+                          "--num_samples", "10", "--guidance_param", "3.0"])
+    assert a.prompt == "a dining chair" and a.watertight and a.guidance_param == 1          # forced back: cond_mask_prob is 0
+    a = sc.generate_args(["--model_path", "m.pt", "--guidance_param", "3.0", "--cond_mask_prob", "0.1"])
+    assert a.guidance_param == 3.0
+    a = sc.generate_args(["--model_path", "m.pt", "--cond_mode", "img", "--image_path", "demo_images/0049.jpg", "--mask_path", "demo_images/0049.png"])
+    assert (a.image_path, a.mask_path, a.category, a.grid_size, a.clip_value) == ("demo_images/0049.jpg", "demo_images/0049.png", 0, 128, 0.1)
+    with pytest.raises(SystemExit):
+        sc.generate_args(["--cond_mode", "no_cond"])                                        # --model_path is required, as upstream
+    import importlib
+    for m in ("uncond", "cat", "text", "image", "sketch"):
+        assert callable(importlib.import_module(f"sample.generate_{m}").main)
+    with pytest.raises(SystemExit, match="drives a 'no_cond' model"):
+        sc.run("uncond", ["--model_path", "m.pt", "--cond_mode", "text"])

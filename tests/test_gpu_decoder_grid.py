@@ -367,6 +367,23 @@ def test_driver_caller_contract_end_to_end(tmp_path, mode, extra):
             assert f.min() >= 0 and f.max() < nv and np.isfinite(v).all()
 
 
+@pytest.mark.parametrize("mode,extra", [("uncond", ["--cond_mode", "no_cond", "--num_samples", "2"]), ("cat", ["--cond_mode", "category", "--category", "5", "--num_samples", "2"]),
+                                        ("text", ["--cond_mode", "text", "--prompt", "a dining chair", "--num_samples", "2", "--cond_mask_prob", "0.1", "--guidance_param", "3.0"])])
+def test_sample_module_command_lines_end_to_end(tmp_path, mode, extra):
+    """python -m sample.generate_{uncond,cat,text}: the reference's own command lines (README.md:39-76) run on the GPU path
+    (synthetic checkpoints in the reference layouts, a short respaced chain, 64^3)."""
+    import importlib
+    mod = importlib.import_module(f"sample.generate_{mode}")
+    latents, written = mod.main(["--model_path", str(tmp_path / "unused.pt"), "--output_dir", str(tmp_path), "--ae_dir", str(tmp_path / "unused_ae.pt"),
+                                 "--resolution", "64", "--synthetic", "--respacing", "ddim20"] + extra)
+    assert latents.shape == (2, 1, 64 if mode == "text" else 32) and len(written) == 2
+    for path, nv, nf in written:
+        v, f = _read_obj(path)
+        assert v.shape == (nv, 3) and f.shape == (nf, 3)
+    if mode == "text":
+        assert all("a-dining-chair_" in w[0] for w in written)
+
+
 def test_get_mesh_from_udf_on_a_known_surface():
     """get_mesh_from_udf with an arbitrary callable (the reference contract) on the analytic thin shell: the mesh lies
     on the surface, is returned as (float32 vertices, int64 faces) on the device, and is an OPEN surface whose border

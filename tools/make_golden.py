@@ -526,6 +526,50 @@ def g15_image_preprocess(R):
     save("g15_image_preprocess", **out)
 
 
+def g16_clip_towers(R):
+    """f4: the reference's vendored CLIP model class (CLIP/clip/model.py) as ViT-B/32 with the seeded weights of
+    surfd_amd.synth.synth_clip_state_dict: encode_image on one seeded 224 x 224 picture batch, encode_text on token
+    rows.  Tokens: the reference's SimpleTokenizer + clip.tokenize(truncate=True) logic on ASCII prompts — the module
+    imports ftfy (absent in this image); ftfy.fix_text is the identity on plain ASCII, so the module is loaded with that
+    one function standing for it, which is stated here and in the test."""
+    import importlib.util
+    import types as _types
+    spec = importlib.util.spec_from_file_location("ref_clip_model", os.path.join("/root/reference", "CLIP", "clip", "model.py"))
+    cm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cm)
+    sd = synth.synth_clip_state_dict(seed=16)
+    model = cm.CLIP(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32, context_length=77,
+                    vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("attn_mask" in k or k in ("input_resolution", "context_length", "vocab_size") for k in missing), (missing, unexpected)
+    img = rnd((2, 3, 224, 224), 1601, 1.0)
+    fake = _types.ModuleType("ftfy")
+    fake.fix_text = lambda t: t
+    sys.modules["ftfy"] = fake
+    try:
+        spec = importlib.util.spec_from_file_location("ref_clip_tok", os.path.join("/root/reference", "CLIP", "clip", "simple_tokenizer.py"))
+        tk = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(tk)
+    finally:
+        del sys.modules["ftfy"]
+    tok = tk.SimpleTokenizer()
+    prompts = ["a dining chair", "A round table with four legs.", "an L-shaped sofa, grey; 3 seats & 2 cushions", "chair",
+               "a very long description " + "of a chair with many many parts " * 12]
+    sot, eot = tok.encoder["<|startoftext|>"], tok.encoder["<|endoftext|>"]
+    tokens = torch.zeros(len(prompts), 77, dtype=torch.long)
+    for i, t in enumerate(prompts):                      # clip.tokenize(texts, truncate=True), CLIP/clip/clip.py:205-245
+        ids = [sot] + tok.encode(t) + [eot]
+        if len(ids) > 77:
+            ids = ids[:77]
+            ids[-1] = eot
+        tokens[i, :len(ids)] = torch.tensor(ids)
+    with torch.no_grad():
+        fi = model.encode_image(img)
+        ft = model.encode_text(tokens)
+    save("g16_clip_towers", seed=np.array(16), image_seed=np.array(1601), image_features=fi, tokens=tokens, text_features=ft,
+         prompts=np.array(prompts))
+
+
 XATTN_CASES = [   # name, query_dim, context_dim (None: self), heads, dim_head, b, n, m, masked
     ("self_small", 64, None, 4, 32, 2, 48, 48, False),
     ("cross_ldm", 320, 512, 8, 64, 3, 32, 77, True),            # LDM's usual text-conditioning shape
@@ -574,7 +618,7 @@ def main():
     jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
             "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
             "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R),
-            "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g15": lambda: g15_image_preprocess(R), "g14": lambda: g14_cross_attention(R)}
+            "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g15": lambda: g15_image_preprocess(R), "g16": lambda: g16_clip_towers(R), "g14": lambda: g14_cross_attention(R)}
     only = [s for s in a.only.split(",") if s]
     for name, fn in jobs.items():
         if only and name not in only:
