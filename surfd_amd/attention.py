@@ -84,3 +84,76 @@ class CrossAttention(nn.Module):
                 N.lib().surfd_xattn_destroy(self._handle)
         except Exception:                                   # interpreter shutdown
             pass
+
+
+class GEGLU(nn.Module):
+    """x -> a * gelu(g) with (a, g) = proj(x) split in halves (modules/attention.py:37-44)."""
+
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x: Tensor) -> Tensor:
+        a, g = self.proj(x).chunk(2, dim=-1)
+        return a * torch.nn.functional.gelu(g)
+
+
+class FeedForward(nn.Module):
+    """modules/attention.py:47-64: (Linear + GELU | GEGLU) -> Dropout -> Linear, same `net.{0,2}` parameter names."""
+
+    def __init__(self, dim: int, dim_out: Optional[int] = None, mult: int = 4, glu: bool = False, dropout: float = 0.0):
+        super().__init__()
+        inner = int(dim * mult)
+        dim_out = dim if dim_out is None else dim_out
+        first = GEGLU(dim, inner) if glu else nn.Sequential(nn.Linear(dim, inner), nn.GELU())
+        self.net = nn.Sequential(first, nn.Dropout(dropout), nn.Linear(inner, dim_out))
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.net(x)
+
+
+class BasicTransformerBlock(nn.Module):
+    """Pre-norm self-attention, cross-attention (self when no context) and gated feed-forward, each with a residual
+    (modules/attention.py:196-216), the two attentions on the native MFMA op.  Same state_dict keys as the reference
+    (attn1.*, attn2.*, ff.net.*, norm1-3.*).  The LayerNorms and the feed-forward are library ops: the block is not on
+    the sampling path of any Surf-D configuration (use_spatial_transformer=False everywhere, models/mdm.py:34-57)."""
+
+    def __init__(self, dim: int, n_heads: int, d_head: int, dropout: float = 0.0, context_dim: Optional[int] = None, gated_ff: bool = True,
+                 checkpoint: bool = True):
+        super().__init__()
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, context: Optional[Tensor] = None) -> Tensor:
+        x = self.attn1(self.norm1(x).contiguous()) + x
+        x = self.attn2(self.norm2(x).contiguous(), context=context) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class SpatialTransformer(nn.Module):
+    """modules/attention.py:219-261: GroupNorm(32, eps 1e-6) -> 1x1 conv -> tokens [b, h*w, c] -> `depth` transformer
+    blocks -> back to the map -> 1x1 conv -> + input.  Same constructor and state_dict keys as the reference."""
+
+    def __init__(self, in_channels: int, n_heads: int, d_head: int, depth: int = 1, dropout: float = 0.0, context_dim: Optional[int] = None):
+        super().__init__()
+        inner = n_heads * d_head
+        self.in_channels = in_channels
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner, kernel_size=1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim)
+                                                 for _ in range(depth)])
+        self.proj_out = nn.Conv2d(inner, in_channels, kernel_size=1)
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, context: Optional[Tensor] = None) -> Tensor:
+        b, c, h, w = x.shape
+        t = self.proj_in(self.norm(x)).flatten(2).transpose(1, 2).contiguous()          # b (h w) c
+        for blk in self.transformer_blocks:
+            t = blk(t, context=context)
+        t = t.transpose(1, 2).reshape(b, -1, h, w)
+        return self.proj_out(t) + x

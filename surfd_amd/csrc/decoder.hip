@@ -187,9 +187,11 @@ struct WStages { f16x8 b[4][4][2]; };        // D = 4 stages x 4 channel tiles x
 #define SURFD_DEC_WS_AHEAD 0
 #endif
 constexpr int WS_AHEAD = SURFD_DEC_WS_AHEAD;
-// where the left-out stages are requested: 1 = by the caller before the barrier in front of the GEMM, 0 = when the GEMM starts
+// where the left-out stages are requested: 0 = when the GEMM starts, 1 = by the caller before the barrier in front of the
+// GEMM, 2 = the first of them before that barrier and the others at the start (measured, profiles/r03_decoder_variants.md:
+// forward 425 / 392-410 / 434 TFLOP/s; 2 leaves the forward kernel without a single spilled register)
 #ifndef SURFD_DEC_REQ_EARLY
-#define SURFD_DEC_REQ_EARLY 0
+#define SURFD_DEC_REQ_EARLY 2
 #endif
 constexpr bool REQ_EARLY = SURFD_DEC_REQ_EARLY != 0;
 constexpr int REQ_EARLY_UPTO = SURFD_DEC_REQ_EARLY == 2 ? WS_AHEAD + 1 : 3;      // 2: only the first left-out stage goes early, the rest at GEMM start

@@ -152,3 +152,20 @@ def synth_clip_state_dict(seed: int = 0, embed_dim: int = 512, image_resolution:
     put("text_projection", (transformer_width, embed_dim), transformer_width ** -0.5)
     sd["logit_scale"] = torch.tensor(2.6592)
     return sd
+
+
+def synth_like(shapes: Dict[str, tuple], seed: int = 0, tag: str = "like") -> Dict[str, torch.Tensor]:
+    """Seeded tensors for an arbitrary parameter table {key: shape}: normalisation scales around 1, other vectors small,
+    matrices / conv kernels with fan-in scaling — one generator per key, so the result does not depend on key order."""
+    out: Dict[str, torch.Tensor] = {}
+    for key, shape in shapes.items():
+        shape = tuple(shape)
+        if len(shape) <= 1:
+            is_scale = "norm" in key and key.endswith("weight")
+            out[key] = _normal(shape, 0.05, f"{tag}.{key}", seed, mean=1.0 if is_scale else 0.0)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            out[key] = _normal(shape, fan_in ** -0.5, f"{tag}.{key}", seed)
+    return out

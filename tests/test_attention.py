@@ -70,3 +70,24 @@ def test_native_cross_attention_vs_oracle(b, n, m, qd, cd, heads, dh):
     with pytest.raises(RuntimeError):
         CrossAttention(64, 64, heads=2, dim_head=256).cuda()(torch.zeros(1, 4, 64).cuda())
     assert mod(torch.zeros(0, n, qd).cuda()).shape == (0, n, qd)
+
+
+@pytest.mark.gpu
+def test_spatial_transformer_vs_reference_fixture(golden):
+    """a19 wrappers (modules/attention.py:37-64, 196-261): SpatialTransformer with BasicTransformerBlock / GEGLU around the
+    native attention op reproduces the reference module's output on seeded weights (self-attention depth 1, cross-attention
+    depth 2), and carries the reference's parameter names."""
+    from surfd_amd.attention import SpatialTransformer
+    g = golden("g17_spatial_transformer")
+    for name in ("self_d1", "cross_d2"):
+        c, heads, dh, depth, ctx_dim, b, h, w, m = (int(v) for v in g[name + "__cfg"])
+        mod = SpatialTransformer(c, heads, dh, depth=depth, context_dim=ctx_dim or None).eval()
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        assert "transformer_blocks.0.ff.net.0.proj.weight" in shapes and "transformer_blocks.0.attn2.to_k.weight" in shapes
+        mod.load_state_dict(synth.synth_like(shapes, seed=int(g[name + "__weight_seed"]), tag="g17"), strict=True)
+        mod = mod.cuda()
+        x = torch.from_numpy(g[name + "__x"]).cuda()
+        ctx = torch.from_numpy(g[name + "__ctx"]).cuda() if name + "__ctx" in g.files else None
+        y = mod(x, context=ctx).cpu().numpy()
+        ref = g[name + "__y"]
+        assert np.abs(y - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (name, float(np.abs(y - ref).max()))

@@ -1,0 +1,42 @@
+"""Register / scratch budget of the hot kernels, read from the gfx950 code objects inside libsurfd_hip.so (ELF notes; no
+GPU needed).  VERDICT r2: the f16x2 decoder kernels spilled 132 / 371 registers; a spilled weight stage inside a GEMM is a
+drain of the software-pipelined weight stream.  The forward kernel must not spill at all, the gradient kernel (both
+accumulator sets + 11 layers of ReLU gates) stays within a bound, the reverse loop's conv kernel keeps two workgroups per CU."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def meta():
+    spec = importlib.util.spec_from_file_location("kernel_regs", os.path.join(ROOT, "tools", "kernel_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kernel_metadata()
+
+
+def _one(meta, prefix):
+    hits = [v for k, v in meta.items() if k.startswith(prefix)]
+    assert len(hits) == 1, (prefix, [k for k in meta if prefix.split("<")[0] in k])
+    return hits[0]
+
+
+def test_forward_decoder_kernel_does_not_spill(meta):
+    k = _one(meta, "void surfd::decoder_kernel<false, true>")
+    assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0 and k[".sgpr_spill_count"] == 0
+    assert k[".vgpr_count"] <= 512
+
+
+def test_gradient_decoder_kernel_spill_bound(meta):
+    k = _one(meta, "void surfd::decoder_kernel<true, true>")
+    assert k[".vgpr_spill_count"] <= 128          # round 2: 371; all of it in the epilogues, none inside a GEMM loop
+
+
+def test_conv_kernels_keep_two_workgroups_per_cu(meta):
+    for name in ("void surfd::conv2_kernel<8, false, false>", "void surfd::conv2_kernel<8, false, true>"):
+        k = _one(meta, name)
+        assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0
+        assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256          # 2 waves per SIMD

@@ -1,0 +1,7 @@
+O=gpurun_out/r3h; mkdir -p $O
+python tools/dec_time.py 22 > $O/dec_variants.txt 2>/dev/null
+SURFD_LIB=$PWD/surfd_amd/lib/variants/libsurfd_hip_e1.so python tools/dec_time.py 22 >> $O/dec_variants.txt 2>/dev/null
+python tools/dec_time.py 22 >> $O/dec_variants.txt 2>/dev/null
+SURFD_LIB=$PWD/surfd_amd/lib/variants/libsurfd_hip_e1.so python tools/dec_time.py 22 >> $O/dec_variants.txt 2>/dev/null
+cat $O/dec_variants.txt
+timeout 900 python -m pytest tests/test_gpu_decoder_grid.py -x -q -m gpu -k "sample_module or driver" > $O/pytest_cli.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_cli.log

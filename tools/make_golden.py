@@ -570,6 +570,28 @@ def g16_clip_towers(R):
          prompts=np.array(prompts))
 
 
+def g17_spatial_transformer(R):
+    """a19 wrappers: the reference's SpatialTransformer / BasicTransformerBlock / GEGLU (modules/attention.py:37-64,
+    196-261) on seeded weights (every parameter, incl. the zero-initialised proj_out, drawn from seeded normals) and inputs,
+    self- and cross-attention variants."""
+    from modules import attention as ratt
+    out = {}
+    for name, (c, heads, dh, depth, ctx_dim, b, h, w, m) in {"self_d1": (64, 4, 16, 1, None, 2, 6, 5, 0), "cross_d2": (96, 3, 32, 2, 40, 2, 4, 8, 7)}.items():
+        mod = ratt.SpatialTransformer(c, heads, dh, depth=depth, context_dim=ctx_dim).eval()
+        sd = synth.synth_like({k: tuple(v.shape) for k, v in mod.state_dict().items()}, seed=1700 + len(name), tag="g17")
+        mod.load_state_dict(sd, strict=True)
+        x = rnd((b, c, h, w), 1750 + len(name))
+        ctx = None if ctx_dim is None else rnd((b, m, ctx_dim), 1760 + len(name))
+        with torch.no_grad():
+            y = mod(x, context=ctx)
+        out[name + "__cfg"] = np.array([c, heads, dh, depth, ctx_dim or 0, b, h, w, m])
+        out[name + "__x"], out[name + "__y"] = x, y
+        if ctx is not None:
+            out[name + "__ctx"] = ctx
+        out[name + "__weight_seed"] = np.array(1700 + len(name))
+    save("g17_spatial_transformer", **out)
+
+
 XATTN_CASES = [   # name, query_dim, context_dim (None: self), heads, dim_head, b, n, m, masked
     ("self_small", 64, None, 4, 32, 2, 48, 48, False),
     ("cross_ldm", 320, 512, 8, 64, 3, 32, 77, True),            # LDM's usual text-conditioning shape
@@ -618,7 +640,7 @@ def main():
     jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
             "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
             "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R),
-            "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g15": lambda: g15_image_preprocess(R), "g16": lambda: g16_clip_towers(R), "g14": lambda: g14_cross_attention(R)}
+            "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g15": lambda: g15_image_preprocess(R), "g16": lambda: g16_clip_towers(R), "g17": lambda: g17_spatial_transformer(R), "g14": lambda: g14_cross_attention(R)}
     only = [s for s in a.only.split(",") if s]
     for name, fn in jobs.items():
         if only and name not in only:
