@@ -24,6 +24,8 @@
 #include "points.h"
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace surfd {
 
@@ -84,7 +86,26 @@ __host__ __device__ constexpr size_t hf_off_fc(int k, int which) { return HF_FCP
 __host__ __device__ constexpr size_t hf_off_fcT(int k, int which) { return HF_FCP + (size_t)(2 * NB + 2 * k + which) * HF_HH; }
 constexpr size_t WHF_ELEMS = HF_FCP + (size_t)4 * NB * HF_HH;
 constexpr int VOFF_SC = VOFF_BOUT + 1;        // SC, 1/SC (floats) and max|W| bits, after b_out
-__host__ __device__ constexpr int slot_channel(int s) { return 128 * (s >> 7) + 64 * ((s >> 6) & 1) + 32 * (s & 1) + ((s >> 1) & 31); }
+// SURFD_DEC_OVL (experiment, default OFF): the k-slot order puts the first two channel tiles of EVERY wave into the first
+// half of K,   slot s -> channel 128*((s>>6)&3) + 32*(2*(s>>8) + (s&1)) + ((s>>1)&31),
+// so that a GEMM can start on the half of its operand that the preceding epilogue has finished while the other half of
+// that epilogue is issued BETWEEN the MFMAs of the GEMM's first half (forward kernel, below).  Built, bit-correct (every
+// decoder / grid test green), measured (profiles/r03_decoder_variants.md): 435 vs 429-434 TFLOP/s.  The phase stamps say why:
+// the half-epilogue costs the same ~3.5 k cycles inside the GEMM as in front of it.  With ONE wave per SIMD every
+// instruction issued between two MFMAs opens a ~6-cycle bubble in the matrix pipe (MI355X_MICROARCH.md: "between MFMAs on
+// DIFFERENT accumulators ~6 cyc/state"; the same 6 cycles x 12 memory instructions per 24 MFMAs are the GEMM loops' own 9 %
+// loss) — vector work does not hide under the same wave's MFMAs; it would take a second wave per SIMD, i.e. half the
+// registers per wave.  Kept as the record of that measurement; costs 25 spilled registers, so it is not the default.
+#ifndef SURFD_DEC_OVL
+#define SURFD_DEC_OVL 0
+#endif
+constexpr bool DEC_OVL = SURFD_DEC_OVL != 0;
+__host__ __device__ constexpr int slot_channel(int s) {
+    return DEC_OVL ? 128 * ((s >> 6) & 3) + 32 * (2 * (s >> 8) + (s & 1)) + ((s >> 1) & 31)
+                   : 128 * (s >> 7) + 64 * ((s >> 6) & 1) + 32 * (s & 1) + ((s >> 1) & 31);
+}
+constexpr int XW_WAVE = DEC_OVL ? 32 : 64;     // word stride of a wave's / of a tile pair's block inside one fp16 plane of an X row
+constexpr int XW_Q = DEC_OVL ? 128 : 32;
 
 struct DecParams {
     const float *wpack;   // WPACK_FLOATS
@@ -287,6 +308,77 @@ __device__ __forceinline__ void gemm_2x4_f16x2(const float *A, const _Float16 *W
     group(KS - D, std::true_type{});
 }
 
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// k-steps [BEG, BEG + 16) of a 32-step GEMM (forward kernel with SURFD_DEC_OVL).  BEG = 0: stage 0 was requested by the
+// caller before the barrier, stages 1 and 2 are requested here; BEG = 16 continues the ring across the barrier in between.
+// WITH_CHUNKS: fully unrolled, chunk(idx) (idx = k-step - BEG, a compile-time constant) contributes a slice of the preceding
+// epilogue's second half to every k-step's scheduling region — 2 value pairs = ~30 vector / LDS instructions next to 24
+// MFMAs of 32 cycles each, i.e. in issue slots the matrix pipe leaves free.
+template <int BEG, bool WITH_CHUNKS, typename ChunkFn>
+__device__ __forceinline__ void gemm_half_f16x2(const float *A, const _Float16 *Whf, WStages &ws, f32x16 (&acc)[2][4], int lane, ChunkFn &&chunk) {
+    constexpr int D = 4, KS = KS_H, END = BEG + 16;
+    const float *a0 = A + (lane & 31) * XS + 4 * (lane >> 5);
+    const float *a1 = a0 + 32 * XS;
+    unsigned lofs = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lofs));
+    f16x8 x[2][2][2];
+    auto load_x = [&](f16x8 (&dst)[2][2], int ks) {
+        dst[0][0] = *reinterpret_cast<const f16x8 *>(a0 + ks * 8); dst[0][1] = *reinterpret_cast<const f16x8 *>(a0 + 256 + ks * 8);
+        dst[1][0] = *reinterpret_cast<const f16x8 *>(a1 + ks * 8); dst[1][1] = *reinterpret_cast<const f16x8 *>(a1 + 256 + ks * 8);
+    };
+    load_x(x[0], BEG);
+    if constexpr (BEG == 0) {
+#pragma unroll
+        for (int d = REQ_EARLY ? REQ_EARLY_UPTO : 0; d < D - 1; ++d) load_wstage<KS>(ws.b[d], Whf, lofs, d);
+    }
+    if constexpr (WITH_CHUNKS) {
+        static_for<16>([&](auto idx) {
+            constexpr int ks = BEG + decltype(idx)::value, j = ks % D;
+            if constexpr (ks + D - 1 < KS) load_wstage<KS>(ws.b[(j + D - 1) % D], Whf, lofs, ks + D - 1);
+            if constexpr (ks + 1 < END) load_x(x[(ks + 1) & 1], ks + 1);
+            chunk(idx);
+            mfma_step_f16x2(x[ks & 1], ws.b[j], acc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    } else {
+        auto group = [&](int ks0, auto last) {
+            int goff = ks0 * 8;
+            asm volatile("" : "+v"(goff));
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                // (the last group of the matrix has one stage left to request, at j = 0)
+                if (!decltype(last)::value || j == 0) load_wstage<KS>(ws.b[(j + D - 1) % D], Whf, lofs, ks0 + j + D - 1);
+                const int jn = (decltype(last)::value && j == D - 1) ? j : j + 1;
+                x[(j + 1) & 1][0][0] = *reinterpret_cast<const f16x8 *>(a0 + goff + jn * 8); x[(j + 1) & 1][0][1] = *reinterpret_cast<const f16x8 *>(a0 + goff + 256 + jn * 8);
+                x[(j + 1) & 1][1][0] = *reinterpret_cast<const f16x8 *>(a1 + goff + jn * 8); x[(j + 1) & 1][1][1] = *reinterpret_cast<const f16x8 *>(a1 + goff + 256 + jn * 8);
+                mfma_step_f16x2(x[j & 1], ws.b[j], acc);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        static_assert(END == KS, "the rolled half is the second one");
+#pragma unroll 1
+        for (int ks0 = BEG; ks0 < END - D; ks0 += D) group(ks0, std::false_type{});
+        group(END - D, std::true_type{});
+    }
+}
+
 // one 32x32 tile: rows = points [32*mt, +32), cols = packed tile `Wp_tile`
 template <int KG>
 __device__ __forceinline__ void gemm_1x1(const float *A, int astride, int mt, const gfloat *Wp_tile, f32x16 &acc, int lane) {
@@ -352,17 +444,17 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
 #define XAT(mt, nt, r) ((mt) ? xb1 : xb0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (nt)]
     // f16x2 mode: word (wave, q, col) of plane `pl` in the same rows (see the layout comment at the top)
     typedef unsigned __attribute__((address_space(3))) lds_u32;
-    lds_u32 *xw0 = (lds_u32 *)(reinterpret_cast<unsigned *>(X) + (4 * (lane >> 5)) * XS + 64 * wave + col);
+    lds_u32 *xw0 = (lds_u32 *)(reinterpret_cast<unsigned *>(X) + (4 * (lane >> 5)) * XS + XW_WAVE * wave + col);
     lds_u32 *xw1 = xw0 + 32 * XS;
-#define XW(mt, q, r, pl) ((mt) ? xw1 : xw0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (q) + 256 * (pl)]
+#define XW(mt, q, r, pl) ((mt) ? xw1 : xw0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + XW_Q * (q) + 256 * (pl)]
     // X <- split(min(relu(a*v + b), 65504)) for this wave's accumulator footprint (a, b per channel tile).
     // Scalar fp32 ops on purpose: packed-f32 ops would need register pairs built from two accumulator
     // tiles (copies + spills), and this mode has no bitwise contract, so the affine map is one fma.
     int sat_flag = 0;      // wave-uniform: some lane of this wave produced an activation beyond the fp16 range (f16x2 mode)
-    auto store_split = [&](const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4], unsigned *mk = nullptr) {
+    auto store_split = [&](const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4], unsigned *mk, auto qn) {
         float umax = 0.f;  // local to one epilogue: a value kept across the GEMM loops would cost spills in the hot loop
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < decltype(qn)::value; ++q)          // qn = 1: only the tile pair that forms the first half of K (SURFD_DEC_OVL)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 if constexpr (!GRAD && !FWD_STAGED) {
@@ -420,6 +512,27 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                 }
             }
         sat_flag |= __any(umax > 65504.f);
+    };
+    // two value pairs of the SECOND tile pair (q = 1) of an epilogue, for the scheduling region of k-step `idx` of the next
+    // GEMM's first half (gemm_half_f16x2): pair pi = 2 idx + i -> point tile pi >> 4, accumulator register pi & 15
+    auto split_chunk = [&](auto idx, const f32x16 (&v)[2][4], const float (&sa)[4], const float (&sb)[4], float &umax) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            constexpr int base = 2 * decltype(idx)::value;
+            const int mt = (base + i) >> 4, r = (base + i) & 15;
+            const float t0 = __builtin_fmaf(sa[2], v[mt][2][r], sb[2]);
+            const float t1 = __builtin_fmaf(sa[3], v[mt][3][r], sb[3]);
+            umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));
+            const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
+            const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
+            const f32x2 u = {u0, u1};
+            const f16x2 h = __builtin_convertvector(u, f16x2);
+            const f32x2 hf = __builtin_convertvector(h, f32x2);
+            const f32x2 rr = {u0 - hf.x, u1 - hf.y};
+            const f16x2 l = __builtin_convertvector(rr, f16x2);
+            XW(mt, 1, r, 0) = __builtin_bit_cast(unsigned, h);
+            XW(mt, 1, r, 1) = __builtin_bit_cast(unsigned, l);
+        }
     };
 
     WStages ws;
@@ -554,6 +667,61 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
         TPHASE(1);
         TBAR();   // E (aliasing X) fully consumed
         // ---- 4. residual blocks ---------------------------------------------------------------
+        if constexpr (F16X2 && !GRAD && DEC_OVL) {
+            // Forward kernel, overlapped form.  Per GEMM: the half of the preceding epilogue that produces the FIRST half of K
+            // (tile pair q = 0 of every wave) is exposed; the GEMM then starts on that half while the other half of the epilogue
+            // (q = 1: words [128, 256) of both planes, which nobody reads before the barrier in the middle of the GEMM) runs in
+            // the MFMAs' shadow; the second half of K follows behind that barrier.  Hazards: an epilogue's q = 0 half rewrites
+            // words [0, 128) — last read by the first half of the previous GEMM, which every wave left before the barrier in
+            // that GEMM's middle; its q = 1 half rewrites words [128, 256) — last read by the previous GEMM's second half,
+            // which every wave left before the barrier behind this epilogue's q = 0 half.  Four barriers per block, as before.
+            const size_t woff = (size_t)(4 * wave_u) * KS_H * 2 * 512;
+#pragma unroll 1
+            for (int k = 0; k < NB; ++k) {
+                const _Float16 *W0 = whf + (HF_FCP + (size_t)(2 * k) * HF_HH) + woff, *W1 = W0 + HF_HH;
+                float sa[4], sb[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { sa[nt] = nsa[nt]; sb[nt] = nsb[nt]; }
+                store_split(net, sa, sb, nullptr, std::integral_constant<int, 1>{});
+                gemm_request_f16x2<KS_H>(ws, W0, lane);
+                TPHASE(2);
+                TBAR();
+                zero_acc(tmp);
+                float sa1[4], sbb[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const unsigned c = cb + 32 * nt;
+                    const float a = tab[(2 * k + 1) * 2 * H + c];
+                    sa1[nt] = a * winv;
+                    sbb[nt] = __builtin_fmaf(a, vecs[H * (1 + 2 * k) + c], tab[(2 * k + 1) * 2 * H + H + c]);      // a*(t/SC + bias0) + b
+                }
+                float um = 0.f;
+                gemm_half_f16x2<0, true>(X, W0, ws, tmp, lane, [&](auto idx) { split_chunk(idx, net, sa, sb, um); });
+                sat_flag |= __any(um > 65504.f);
+                TPHASE(1);
+                TBAR();
+                gemm_half_f16x2<16, false>(X, W0, ws, tmp, lane, [](auto) {});
+                store_split(tmp, sa1, sbb, nullptr, std::integral_constant<int, 1>{});
+                gemm_request_f16x2<KS_H>(ws, W1, lane);
+                TPHASE(2);
+                TBAR();
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const unsigned c = cb + 32 * nt;
+                    const float a = tab[(2 * k + 2) * 2 * H + c];                // next block's first CBN (or the final one)
+                    nsa[nt] = a * winv;
+                    nsb[nt] = __builtin_fmaf(a, vecs[voff_cb(0) + H * (k + 1) + c], tab[(2 * k + 2) * 2 * H + H + c]);   // biases so far, folded
+                }
+                um = 0.f;
+                gemm_half_f16x2<0, true>(X, W1, ws, net, lane, [&](auto idx) { split_chunk(idx, tmp, sa1, sbb, um); });
+                sat_flag |= __any(um > 65504.f);
+                TPHASE(1);
+                TBAR();
+                gemm_half_f16x2<16, false>(X, W1, ws, net, lane, [](auto) {});
+            }
+            TPHASE(1);
+            TBAR();        // every wave is done reading X before the final layer rewrites it
+        } else {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             // X <- relu(a*net + b), layer 2k
@@ -565,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                 if constexpr (F16X2) {
                     unsigned *mk = nullptr;
                     if constexpr (GRAD) mk = msk[2 * k];
-                    store_split(net, sa, sb, mk);
+                    store_split(net, sa, sb, mk, std::integral_constant<int, 2>{});
                 } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -608,7 +776,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                     for (int nt = 0; nt < 4; ++nt) sbb[nt] = __builtin_fmaf(sa[nt], bias[nt], sb[nt]);
                     unsigned *mk = nullptr;
                     if constexpr (GRAD) mk = msk[2 * k + 1];
-                    store_split(tmp, sa, sbb, mk);
+                    store_split(tmp, sa, sbb, mk, std::integral_constant<int, 2>{});
                 } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -658,6 +826,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
             TPHASE(1);
             TBAR();
         }
+        }      // (non-overlapped form)
         // ---- 5. final CBN + ReLU + fc_out (512 -> 1) -----------------------------------------
         float wo[4], a10[4];
         {
