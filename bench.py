@@ -305,12 +305,13 @@ def time_trace(dec, lat, lists, reps=2):
 def committed_traffic():
     """HBM traffic of the dominant kernel from the committed PMC pass of this command (profiles/, collected in its
     own rocprofv3 --pmc run as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per the gfx950 note)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(path):
-        try:
-            return json.load(open(path))
-        except (OSError, ValueError):
-            return None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                return json.load(open(path))
+            except (OSError, ValueError):
+                continue
     return None
 
 

@@ -1100,6 +1100,316 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
 }
 
 #undef XAT
+
+// =============================================================================================================================
+// Forward kernel, 8-wave form (f16x2): 512 threads = TWO waves per SIMD on the same 64-point x 512-channel tile.
+// Wave w owns channels [64 w, 64 w + 64): 2 (point tiles) x 2 (channel tiles) accumulators for the residual stream and as
+// many for the block intermediate (128 of its 256 registers), 4 weight stages of 2 x 2 fragments, the same X rows in LDS
+// (a wave's tile pair is one 32-bit word column: word 32 w + col of both planes — the k-slot order of the 4-wave kernels is
+// exactly this order, so the packed weights are shared).  Why: with one wave per SIMD nothing hides behind anything — every
+// load or LDS read issued between two MFMAs idles the matrix pipe for ~6 cycles (9 % of every GEMM), and an epilogue is a
+// single dependent instruction stream at ~8 cycles per instruction (22 % of a tile; profiles/r03_decoder_variants.md).  With
+// two waves per SIMD the partner's MFMAs fill the issue bubbles of a GEMM and the two epilogue streams interleave.  No
+// weight byte is fetched twice (the eight waves partition the 512 output channels); each wave reads all of X, so the LDS
+// read traffic doubles (32 KB per k-step pair: 42 B/clk/CU of the 256 the LDS delivers).
+// =============================================================================================================================
+struct WStages8 { f16x8 b[4][2][2]; };        // 4 stages x 2 channel tiles x 2 planes (64 registers)
+
+template <int KS>
+__device__ __forceinline__ void load_wstage8(f16x8 (&dst)[2][2], const _Float16 *Whf, unsigned lofs, int ks) {
+    const unsigned long long wa = (unsigned long long)Whf;
+    unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)wa), whi = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32));
+    asm volatile("" : "+s"(wlo), "+s"(whi));
+    const __attribute__((address_space(1))) char *wb = (const __attribute__((address_space(1))) char *)(((unsigned long long)whi << 32) | wlo);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            dst[nt][q] = *reinterpret_cast<const gf16x8 *>(wb + (size_t)(nt * KS * 2048) + (lofs + (unsigned)((ks * 2 + q) * 1024)));
+}
+
+__device__ __forceinline__ void mfma_step8(const f16x8 (&a)[2][2], const f16x8 (&b)[2][2], f32x16 (&acc)[2][2]) {
+    constexpr int TA[3] = {1, 0, 0};     // activation plane
+    constexpr int TB[3] = {0, 1, 0};     // weight plane (small terms first)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][TA[t]], b[nt][TB[t]], acc[mt][nt], 0, 0, 0);
+}
+
+// stage 0 of a matrix, requested by the caller before the barrier in front of the GEMM (as gemm_request_f16x2)
+template <int KS>
+__device__ __forceinline__ void gemm8_request(WStages8 &ws, const _Float16 *Whf, int lane) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned lofs = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lofs));
+    load_wstage8<KS>(ws.b[0], Whf, lofs, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[mt][nt] += A[64 x 16 KS] (split fp16 planes in LDS) * W (2 channel tiles of this wave); 12 MFMAs per k-step
+template <int KS>
+__device__ __forceinline__ void gemm8(const float *A, const _Float16 *Whf, WStages8 &ws, f32x16 (&acc)[2][2], int lane) {
+    constexpr int D = 4;
+    static_assert(KS % D == 0, "k-step count must be a multiple of the pipeline depth");
+    const float *a0 = A + (lane & 31) * XS + 4 * (lane >> 5);
+    const float *a1 = a0 + 32 * XS;
+    unsigned lofs = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lofs));
+    f16x8 x[2][2][2];
+    auto group = [&](int ks0, auto last) {
+        int goff = ks0 * 8;
+        asm volatile("" : "+v"(goff));
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (!decltype(last)::value || j == 0) load_wstage8<KS>(ws.b[(j + D - 1) % D], Whf, lofs, ks0 + j + D - 1);
+            const int jn = (decltype(last)::value && j == D - 1) ? j : j + 1;
+            x[(j + 1) & 1][0][0] = *reinterpret_cast<const f16x8 *>(a0 + goff + jn * 8); x[(j + 1) & 1][0][1] = *reinterpret_cast<const f16x8 *>(a0 + goff + 256 + jn * 8);
+            x[(j + 1) & 1][1][0] = *reinterpret_cast<const f16x8 *>(a1 + goff + jn * 8); x[(j + 1) & 1][1][1] = *reinterpret_cast<const f16x8 *>(a1 + goff + 256 + jn * 8);
+            mfma_step8(x[j & 1], ws.b[j], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    x[0][0][0] = *reinterpret_cast<const f16x8 *>(a0); x[0][0][1] = *reinterpret_cast<const f16x8 *>(a0 + 256);
+    x[0][1][0] = *reinterpret_cast<const f16x8 *>(a1); x[0][1][1] = *reinterpret_cast<const f16x8 *>(a1 + 256);
+    if constexpr (KS > D) {
+#pragma unroll
+        for (int d = 1; d < D - 1; ++d) load_wstage8<KS>(ws.b[d], Whf, lofs, d);
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KS - D; ks0 += D) group(ks0, std::false_type{});
+        group(KS - D, std::true_type{});
+    } else {
+        // the 4-step first layer: all of its stages at once (stage 0 came early), then one group without further requests
+#pragma unroll
+        for (int d = 1; d < D; ++d) load_wstage8<KS>(ws.b[d], Whf, lofs, d);
+        int goff = 0;
+        asm volatile("" : "+v"(goff));
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int jn = j == D - 1 ? j : j + 1;
+            x[(j + 1) & 1][0][0] = *reinterpret_cast<const f16x8 *>(a0 + goff + jn * 8); x[(j + 1) & 1][0][1] = *reinterpret_cast<const f16x8 *>(a0 + goff + 256 + jn * 8);
+            x[(j + 1) & 1][1][0] = *reinterpret_cast<const f16x8 *>(a1 + goff + jn * 8); x[(j + 1) & 1][1][1] = *reinterpret_cast<const f16x8 *>(a1 + goff + 256 + jn * 8);
+            mfma_step8(x[j & 1], ws.b[j], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBatch B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *X = lds;                      // [TP][XS]
+    float *PT = lds + TP * XS;           // [TP][4]
+    float *LOG = PT + TP * 4;            // [TP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // wave 0..7
+    const int col = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float *const xb0 = X + (4 * (lane >> 5)) * XS + 64 * wave + col;        // fp32 view (final layer)
+    float *const xb1 = xb0 + 32 * XS;
+#define XAT8(mt, nt, r) ((mt) ? xb1 : xb0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (nt)]
+    typedef unsigned __attribute__((address_space(3))) lds_u32;
+    lds_u32 *xw0 = (lds_u32 *)(reinterpret_cast<unsigned *>(X) + (4 * (lane >> 5)) * XS + 32 * wave + col);
+    lds_u32 *xw1 = xw0 + 32 * XS;
+#define XW8(mt, r, pl) ((mt) ? xw1 : xw0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 256 * (pl)]
+    int sat_flag = 0;
+    // X <- split(min(relu(a*v + b), 65504)) for this wave's 64 channels x 64 points
+    auto store8 = [&](const f32x16 (&v)[2][2], const float (&sa)[2], const float (&sb)[2]) {
+        float umax = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t0 = __builtin_fmaf(sa[0], v[mt][0][r], sb[0]);
+                const float t1 = __builtin_fmaf(sa[1], v[mt][1][r], sb[1]);
+                umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));
+                const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
+                const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
+                const f32x2 u = {u0, u1};
+                const f16x2 h = __builtin_convertvector(u, f16x2);
+                const f32x2 hf = __builtin_convertvector(h, f32x2);
+                const f32x2 rr = {u0 - hf.x, u1 - hf.y};
+                const f16x2 l = __builtin_convertvector(rr, f16x2);
+                XW8(mt, r, 0) = __builtin_bit_cast(unsigned, h);
+                XW8(mt, r, 1) = __builtin_bit_cast(unsigned, l);
+            }
+        sat_flag |= __any(umax > 65504.f);
+    };
+    auto zero8 = [](f32x16 (&a)[2][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[mt][nt][r] = 0.f;
+    };
+    WStages8 ws;
+    for (int bi = 0; bi < B.n; ++bi) {
+    const PtIO &io = B.io[bi];
+    const long npts = pt_count(io);
+    const long ntiles = (npts + TP - 1) / TP;
+    const float *tab_sample = P.tab + (size_t)B.sample[bi] * NCBN * 2 * H;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long e0 = tile * TP;
+        const float *vecs_ = P.vecs, *tab_ = tab_sample;
+        const _Float16 *whf = P.whf;
+        unsigned cb = 64 * wave + col;              // first of this lane's two channels (+32 for the second tile)
+        asm volatile("" : "+s"(vecs_), "+s"(tab_), "+s"(whf), "+v"(cb), "+v"(xw0), "+v"(xw1));
+        const gfloat *vecs = (const gfloat *)vecs_, *tab = (const gfloat *)tab_;
+        const size_t woff_e = (size_t)(2 * wave_u) * KS_E * 2 * 512, woff = (size_t)(2 * wave_u) * KS_H * 2 * 512;
+        __syncthreads();        // previous tile's readers of PT / LOG are done
+        // ---- 1. fetch points ------------------------------------------------------------------
+        if (tid < TP) {
+            const long e = e0 + tid;
+            float x = 0.f, y = 0.f, z = 0.f;
+            int vox = -1;
+            if (e < npts) {
+                if (io.mode == PT_XYZ) { x = io.xyz[e * 3 + 0]; y = io.xyz[e * 3 + 1]; z = io.xyz[e * 3 + 2]; vox = 0; }
+                else if (io.mode == PT_EMB) vox = 0;
+                else { vox = pt_voxel(io, e); voxel_xyz(io, vox, x, y, z); }
+            }
+            PT[tid * 4 + 0] = x; PT[tid * 4 + 1] = y; PT[tid * 4 + 2] = z;
+            PT[tid * 4 + 3] = __int_as_float(vox);
+        }
+        __syncthreads();
+        // ---- 2. positional encoding, split planes in X's row layout (identity k-slot order): 8 threads per point ------
+        {
+            const int p = tid >> 3, part = tid & 7;
+            const long e = e0 + p;
+            const float c3[3] = {PT[p * 4 + 0], PT[p * 4 + 1], PT[p * 4 + 2]};
+            auto feature = [&](int j) -> float {
+                if (io.mode == PT_EMB) return (e < npts && j < io.emb_dim) ? io.xyz[e * io.emb_dim + j] : 0.f;
+                if (j < 3) return c3[j];
+                if (j == 63) return 0.f;
+                const int f = (j - 3) / 6, r = (j - 3) % 6;
+                const float a = c3[r % 3] * (float)(1 << f);      // exact: power-of-two scale
+                return (r < 3) ? sinf(a) : cosf(a);
+            };
+            unsigned *row = reinterpret_cast<unsigned *>(X) + p * XS + part * 4;
+#pragma unroll 2
+            for (int i = 0; i < 4; ++i) {
+                f32x2 u = {feature(part * 8 + 2 * i), feature(part * 8 + 2 * i + 1)};
+                sat_flag |= __any(__builtin_fmaxf(__builtin_fabsf(u.x), __builtin_fabsf(u.y)) > 65504.f);
+                u.x = __builtin_amdgcn_fmed3f(u.x, -65504.f, 65504.f);
+                u.y = __builtin_amdgcn_fmed3f(u.y, -65504.f, 65504.f);
+                unsigned hi, lo;
+                split2(u, hi, lo);
+                row[i] = hi;
+                row[256 + i] = lo;
+            }
+        }
+        gemm8_request<KS_E>(ws, whf + woff_e, lane);
+        __syncthreads();
+        // ---- 3. fc_p ---------------------------------------------------------------------------
+        f32x16 net[2][2], tmp[2][2];
+        zero8(net);
+        const float winv = vecs[VOFF_SC + 1];
+        float nsa[2], nsb[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const unsigned c = cb + 32 * nt;
+            const float a = tab[c];
+            nsa[nt] = a * winv;
+            nsb[nt] = __builtin_fmaf(a, vecs[voff_cb(0) + c], tab[H + c]);        // fc_p's bias, folded
+        }
+        gemm8<KS_E>(X, whf + woff_e, ws, net, lane);
+        __syncthreads();        // the encoding (aliasing X) is fully consumed
+        // ---- 4. residual blocks ------------------------------------------------------------------
+#pragma unroll 1
+        for (int k = 0; k < NB; ++k) {
+            const _Float16 *W0 = whf + (HF_FCP + (size_t)(2 * k) * HF_HH) + woff, *W1 = W0 + HF_HH;
+            {
+                float sa[2] = {nsa[0], nsa[1]}, sb[2] = {nsb[0], nsb[1]};
+                store8(net, sa, sb);                                            // X <- relu(a*net + b), layer 2k
+            }
+            gemm8_request<KS_H>(ws, W0, lane);
+            __syncthreads();
+            zero8(tmp);
+            float sa1[2], sbb[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const unsigned c = cb + 32 * nt;
+                const float a = tab[(2 * k + 1) * 2 * H + c];
+                sa1[nt] = a * winv;
+                sbb[nt] = __builtin_fmaf(a, vecs[H * (1 + 2 * k) + c], tab[(2 * k + 1) * 2 * H + H + c]);      // a*(t/SC + bias0) + b
+            }
+            gemm8<KS_H>(X, W0, ws, tmp, lane);
+            __syncthreads();
+            store8(tmp, sa1, sbb);                                              // layer 2k+1
+            gemm8_request<KS_H>(ws, W1, lane);
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const unsigned c = cb + 32 * nt;
+                const float a = tab[(2 * k + 2) * 2 * H + c];                     // next block's first CBN (or the final one)
+                nsa[nt] = a * winv;
+                nsb[nt] = __builtin_fmaf(a, vecs[voff_cb(0) + H * (k + 1) + c], tab[(2 * k + 2) * 2 * H + H + c]);
+            }
+            gemm8<KS_H>(X, W1, ws, net, lane);                                    // net += fc_1(X)
+            __syncthreads();
+        }
+        // ---- 5. final CBN + ReLU + fc_out (512 -> 1) -------------------------------------------------
+        {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float wo = vecs[VOFF_WOUT + cb + 32 * nt];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float u = nsa[nt] * net[mt][nt][r] + nsb[nt];
+                        XAT8(mt, nt, r) = fmaxf(u, 0.f) * wo;
+                    }
+            }
+        }
+        __syncthreads();
+        {
+            const float bo = vecs[VOFF_BOUT];
+            for (int pp = 0; pp < TP / 8; ++pp) {
+                const int p = wave * (TP / 8) + pp;
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < H / 64; ++i) sacc += X[p * XS + lane + 64 * i];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+                if (lane == 0) LOG[p] = sacc + bo;
+            }
+        }
+        __syncthreads();
+        if (tid < TP) {          // exactly wave 0: all 64 lanes reach the aggregated append
+            const long e = e0 + tid;
+            const bool valid = e < npts;
+            float udf = 0.f;
+            int vox = 0;
+            if (valid) {
+                const float o = LOG[tid];
+                const float y = 1.f / (1.f + expf(-o));
+                udf = (1.f - y) * 0.1f;
+                if (io.out_logit) io.out_logit[e] = o;
+                if (io.out_udf) io.out_udf[e] = udf;
+                if (io.grid_udf) {
+                    vox = __float_as_int(PT[tid * 4 + 3]);
+                    io.grid_udf[vox] = udf;
+                }
+            }
+            if (io.grid_udf && io.grad_list) {
+                const int slot = wave_append_slot(io.grad_count, valid && udf < io.grad_thr);
+                if (slot >= 0) io.grad_list[slot] = vox;
+            }
+        }
+    }
+    }
+    if (sat_flag && lane == 0) atomicAdd(P.sat, 1u);
+}
+#undef XAT8
+#undef XW8
+
 #undef XW
 constexpr size_t DEC_LDS_BYTES = (size_t)(TP * XS + TP * 4 + TP + TP * ES + TP * 4 + 4) * sizeof(float);
 
@@ -1197,6 +1507,7 @@ struct surfd_decoder {
     float *wpack = nullptr, *vecs = nullptr;
     _Float16 *whf = nullptr;          // f16x2 planes of the forward matrices (built by finalize)
     int precision = 1;                // forward kernel: 1 = f16x2 (default), 0 = exact fp32 MFMA
+    int fwd8 = 0;                     // f16x2 forward kernel in its 8-wave form (two waves per SIMD); SURFD_DECODER_FWD8
     float *gw[NCBN] = {}, *gb[NCBN] = {}, *bw[NCBN] = {}, *bb[NCBN] = {}, *mean[NCBN] = {}, *var[NCBN] = {};
     float *tab = nullptr;
     int S = 0, tab_cap = 0;
@@ -1239,6 +1550,7 @@ static int dec_alloc(surfd_decoder *d) {
     d->allocs.push_back(d->sat);
     HIP_TRY(hipMemset(d->sat, 0, sizeof(unsigned)));
     if (const char *pe = getenv("SURFD_DECODER_PRECISION")) d->precision = !strcmp(pe, "fp32") ? 0 : 1;
+    if (const char *pe = getenv("SURFD_DECODER_FWD8")) d->fwd8 = atoi(pe) != 0;
     for (int l = 0; l < NCBN; ++l) {
         if ((rc = A(&d->gw[l], (size_t)H * d->D))) return rc;
         if ((rc = A(&d->bw[l], (size_t)H * d->D))) return rc;
@@ -1254,6 +1566,8 @@ static int dec_alloc(surfd_decoder *d) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&decoder_fwd8_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS_BYTES));
     d->allocated = true;
     return SURFD_OK;
@@ -1498,6 +1812,8 @@ int decoder_launch_batch(surfd_decoder *d, const PtBatch &batch, bool grad, long
         hipLaunchKernelGGL((decoder_kernel<true, true>), dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     else if (grad)
         hipLaunchKernelGGL(decoder_kernel<true>, dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
+    else if (d->precision == 1 && d->fwd8)
+        hipLaunchKernelGGL(decoder_fwd8_kernel, dim3((unsigned)blocks), dim3(512), DEC_LDS_BYTES, st, P, io);
     else if (d->precision == 1)
         hipLaunchKernelGGL((decoder_kernel<false, true>), dim3((unsigned)blocks), dim3(256), DEC_LDS_BYTES, st, P, io);
     else

@@ -75,11 +75,11 @@ def test_cpu_model_is_reported(bench):
 
 
 def test_committed_traffic_is_what_the_tool_derives(tmp_path, bench):
-    """roofline.traffic comes from profiles/r02_pmc_traffic.json; that file must be exactly what tools/pmc_to_traffic.py
+    """roofline.traffic comes from profiles/r03_pmc_traffic.json; that file must be exactly what tools/pmc_to_traffic.py
     derives from the committed PMC summary (KiB units, FETCH_SIZE doubled on gfx950), not a hand-edited number."""
     import json
     import subprocess
-    src = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    src = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
     out = tmp_path / "traffic.json"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_to_traffic.py"), src, str(out)],
                           stdout=subprocess.DEVNULL, cwd=ROOT)

@@ -34,9 +34,9 @@ unet_write = sum(pick("write", k).get("WRITE_SIZE", 0) for k in ("conv2_kernel",
 evals = max(pick("fetch", "conv2_kernel")["dispatches"] / CONVS_PER_EVAL, 1)
 c2 = pick("sq", "conv2_kernel")
 out = {
-    "source": (f"{src}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes) over `python bench.py --steps 1 "
-               "--warmup 0 --diffusion-steps 20 --pipeline 0` (same kernels and grid sizes as the headline run; the full command "
-               "under --pmc is ~2.6 M dispatches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
+    "source": (f"{src}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes) over `python bench.py --steps N "
+               "--warmup 0 --diffusion-steps 20 ...` (the shortened command of tools/profile_round.sh: same kernels and grid shapes as the "
+               "headline run, whose full length under --pmc would be hundreds of thousands of serialised dispatches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
                "64 B); counters sit on the L2's fabric side and include Infinity-Cache hits"),
     "decoder_fwd_launches_measured": n_dec,
     "decoder_fwd_fetch_bytes_per_launch": dec_f.get("FETCH_SIZE", 0) * 1024 * 2 / n_dec,
