@@ -179,6 +179,27 @@ __device__ __forceinline__ void split2(const f32x2 u, unsigned &hi, unsigned &lo
 
 typedef f16x8 __attribute__((address_space(1))) gf16x8;
 
+// low fp16 halves of a split pair, packed: f16(u - f32(h)) per half, the subtraction exact in fp32 as in split2 — as two
+// mixed-precision FMAs (h * -1 + u with an fp16 operand and an fp16 result written to one half of the register) instead of
+// two conversions back, a packed subtraction and a packed conversion: 2 instructions instead of 4 per pair in the epilogues
+#ifndef SURFD_DEC_MIX
+#define SURFD_DEC_MIX 1
+#endif
+__device__ __forceinline__ unsigned split_low_pair(unsigned h, float u0, float u1) {
+#if SURFD_DEC_MIX
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l) : "v"(h), "v"(u0), "v"(u1));
+    return l;
+#else
+    const f16x2 hh = __builtin_bit_cast(f16x2, h);
+    const f32x2 hf = __builtin_convertvector(hh, f32x2);
+    const f32x2 rr = {u0 - hf.x, u1 - hf.y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(rr, f16x2));
+#endif
+}
+
 __device__ __forceinline__ void mfma_step_f16x2(const f16x8 (&a)[2][2], const f16x8 (&b)[4][2], f32x16 (&acc)[2][4]) {
     // term-major: the 8 accumulators are independent, so consecutive MFMAs never wait on each other;
     // small terms first
@@ -466,12 +487,9 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                         const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
                         const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
                         const f32x2 u = {u0, u1};
-                        const f16x2 h = __builtin_convertvector(u, f16x2);              // one v_cvt_pk_f16_f32
-                        const f32x2 hf = __builtin_convertvector(h, f32x2);
-                        const f32x2 rr = {u0 - hf.x, u1 - hf.y};
-                        const f16x2 l = __builtin_convertvector(rr, f16x2);
-                        XW(mt, q, r, 0) = __builtin_bit_cast(unsigned, h);
-                        XW(mt, q, r, 1) = __builtin_bit_cast(unsigned, l);
+                        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(u, f16x2));      // one v_cvt_pk_f16_f32
+                        XW(mt, q, r, 0) = h;
+                        XW(mt, q, r, 1) = split_low_pair(h, u0, u1);
                     }
                     continue;
                 }
@@ -1232,12 +1250,9 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
                 const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
                 const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
                 const f32x2 u = {u0, u1};
-                const f16x2 h = __builtin_convertvector(u, f16x2);
-                const f32x2 hf = __builtin_convertvector(h, f32x2);
-                const f32x2 rr = {u0 - hf.x, u1 - hf.y};
-                const f16x2 l = __builtin_convertvector(rr, f16x2);
-                XW8(mt, r, 0) = __builtin_bit_cast(unsigned, h);
-                XW8(mt, r, 1) = __builtin_bit_cast(unsigned, l);
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(u, f16x2));
+                XW8(mt, r, 0) = h;
+                XW8(mt, r, 1) = split_low_pair(h, u0, u1);
             }
         sat_flag |= __any(umax > 65504.f);
     };
@@ -1507,7 +1522,7 @@ struct surfd_decoder {
     float *wpack = nullptr, *vecs = nullptr;
     _Float16 *whf = nullptr;          // f16x2 planes of the forward matrices (built by finalize)
     int precision = 1;                // forward kernel: 1 = f16x2 (default), 0 = exact fp32 MFMA
-    int fwd8 = 0;                     // f16x2 forward kernel in its 8-wave form (two waves per SIMD); SURFD_DECODER_FWD8
+    int fwd8 = 1;                     // f16x2 forward kernel in its 8-wave form (two waves per SIMD: 453 against 438 TFLOP/s); SURFD_DECODER_FWD8=0 selects the 4-wave kernel
     float *gw[NCBN] = {}, *gb[NCBN] = {}, *bw[NCBN] = {}, *bb[NCBN] = {}, *mean[NCBN] = {}, *var[NCBN] = {};
     float *tab = nullptr;
     int S = 0, tab_cap = 0;

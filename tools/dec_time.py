@@ -37,8 +37,10 @@ dec.set_precision("f16x2")
 u16 = dec.udf(pts[: 1 << 18], 1)
 _, n16 = dec.udf_and_ngrad(gp[: 1 << 16], 1)
 cos = (n32 * n16).sum(-1)
+import hashlib
+digest = hashlib.sha256(u16.cpu().numpy().tobytes()).hexdigest()[:12]
 f_ms = timed(lambda: dec.udf(pts, 0))
 g_ms = timed(lambda: dec.udf_and_ngrad(gp, 0))
 print(f"{os.path.basename(os.environ.get('SURFD_LIB', 'default')):28s} fwd {pts.shape[0] * FWD / f_ms / 1e9:6.1f} TF ({f_ms:.2f} ms)  "
       f"fwd+bwd {gp.shape[0] * 2 * FWD / g_ms / 1e9:6.1f} TF ({g_ms:.2f} ms)  max|udf16-udf32| {float((u16 - u32).abs().max()):.2e}  "
-      f"cos>=1-1e-5: {100 * float((cos >= 1 - 1e-5).float().mean()):.3f} %  sat {dec.saturation_count()}", flush=True)
+      f"cos>=1-1e-5: {100 * float((cos >= 1 - 1e-5).float().mean()):.3f} %  sat {dec.saturation_count()}  udf16 sha {digest}", flush=True)
