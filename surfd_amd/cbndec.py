@@ -136,23 +136,25 @@ class CbnDecoder(nn.Module):
         self._handle = None
         self._bound_key = None          # (device, versions) the native copy was made from
         self._latents_key = None
-        self._key_tensors = None
+        self._key_slots = None
 
     # ---- native handle management -------------------------------------------------------------
     def _state_key(self):
-        # the tensor objects are collected once (rebuilding a 101-entry state_dict on every udf call is measurable in
-        # callback mode); .to()/.cuda() replace buffer objects and load_state_dict may too, so both drop the list
-        if self._key_tensors is None:
-            self._key_tensors = [v for _, v in self.state_dict(keep_vars=True).items()]
-        return tuple((v.data_ptr(), v._version) for v in self._key_tensors)
-
-    def _apply(self, fn, *args, **kwargs):
-        self._key_tensors = None
-        return super()._apply(fn, *args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self._key_tensors = None
-        return super().load_state_dict(*args, **kwargs)
+        # (storage address, version) of every tensor of the state_dict.  The SLOTS — (owning dict, leaf name) in state_dict
+        # order — are collected once (the module tree never changes; rebuilding a 101-entry state_dict on every udf call is
+        # measurable in callback mode); the tensors are looked up in them on every call, so any rebinding is seen whether or
+        # not it goes through a hook: `.to()` / `.cuda()`, `load_state_dict(assign=True)` on this module or a parent,
+        # `decoder.blocks.0.fc_0.weight = nn.Parameter(...)`.
+        if self._key_slots is None:
+            slots = []
+            for mod_name, mod in self.named_modules():
+                for name in mod._parameters:
+                    slots.append((mod._parameters, name))
+                for name in mod._buffers:
+                    if name not in mod._non_persistent_buffers_set:
+                        slots.append((mod._buffers, name))
+            self._key_slots = slots
+        return tuple((t.data_ptr(), t._version) for d, n in self._key_slots for t in (d[n],) if t is not None)
 
     def _native(self):
         first = next(self.parameters())

@@ -122,3 +122,24 @@ def test_gridfiller_levels_and_sharding():
     a = synth.synth_noise_batch(5, 0, 4, 8)
     b = synth.synth_noise_batch(5, 2, 2, 8)
     assert torch.equal(a[:, 2:], b)
+
+
+def test_decoder_state_key_sees_rebound_tensors():
+    """the native copy of the decoder weights is refreshed whenever the key changes; the key must change when a
+    parameter OBJECT is replaced without going through .to() / load_state_dict (attribute assignment, assign=True loads)."""
+    import torch
+    from surfd_amd.cbndec import CbnDecoder
+    dec = CbnDecoder(63, 32, 512, 5)
+    k0 = dec._state_key()
+    assert k0 == dec._state_key() and len(k0) == len(dec.state_dict())
+    owner = getattr(dec.decoder.blocks, "0").fc_0
+    owner.weight = torch.nn.Parameter(owner.weight.detach().clone())          # same values, new object
+    k1 = dec._state_key()
+    assert k1 != k0
+    with torch.no_grad():
+        owner.weight.add_(1.0)                                      # in-place: version bump
+    assert dec._state_key() != k1
+    sd = {k: v.clone() for k, v in dec.state_dict().items()}
+    k2 = dec._state_key()
+    dec.load_state_dict(sd, assign=True)
+    assert dec._state_key() != k2
