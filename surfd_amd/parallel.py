@@ -242,7 +242,7 @@ class PhasedPipeline:
         self.loop_fn, self.fill_fn = loop_fn, fill_fn
         self.chains = max(1, int(chains))
         self.max_loop_batches = max(1, int(max_loop_batches))
-        self.loop_streams = [torch.cuda.Stream() for _ in range(self.chains)]
+        self.loop_streams = None                 # created on first run (plan() needs no device)
         self.record_timeline = False
         self.timeline = []
 
@@ -267,6 +267,8 @@ class PhasedPipeline:
         import threading
         if n_batches <= 0:
             return
+        if self.loop_streams is None:
+            self.loop_streams = [torch.cuda.Stream() for _ in range(self.chains)]
         cur = torch.cuda.current_stream()
         dev = torch.cuda.current_device()
         t_begin = None

@@ -537,3 +537,52 @@ def test_wide_form_latent_does_not_depend_on_batch_width(wide_model):
     model.set_wide(0)                                # the latency form agrees to fp32 rounding
     b = model(x, t, y={})
     assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_phased_pipeline_matches_sequential(wide_model):
+    """surfd_amd.parallel.PhasedPipeline (bench.py's default schedule): the reverse loops of a round as two WIDE loops over
+    several steps' latents at once, then the round's grids — every shape's latent, grid and gradients must equal, bit for
+    bit, what one narrow loop per step followed by its grids gives (same conv form), for round sizes that do not divide the
+    number of steps."""
+    from surfd_amd.cbndec import CbnDecoder, make_udf_func
+    from surfd_amd.meshudf import GridFiller
+    from surfd_amd.parallel import PhasedPipeline
+    from surfd_amd.spec import DecoderConfig
+    model, _, _ = wide_model
+    _, dd, _ = _model("no_cond", "ddim20")
+    dec = CbnDecoder(63, 32, 512, 5)
+    dec.load_state_dict(synth.synth_decoder_state_dict(DecoderConfig(latent_dim=32)), strict=True)
+    dec = dec.cuda().eval()
+    B, N, nb = 2, 64, 7
+    filler = GridFiller(N)
+    bank = torch.stack([synth.synth_noise_batch(20, s * B, B, 32) for s in range(nb)], 0).cuda()        # [S, T+1, B, 1, L]
+    rep = model.replica()
+    rep.set_wide(32)
+    chains = [model, rep]
+
+    def loop(first, n, chain=0):
+        noise = bank[first:first + n].permute(1, 0, 2, 3, 4).reshape(21, n * B, 1, 32).contiguous()
+        return dd.ddim_sample_loop(chains[chain], (n * B, 1, 32), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise, fused=True)
+
+    def make_fill(store):
+        def fill(s, lat):
+            dec.bind_latents(lat.reshape(B, 32))
+            for k in range(B):
+                u, g = filler.fill_grid(make_udf_func(dec, lat[k], sample=k), 2 ** 16, stats=False)
+                store[(s, k)] = (lat[k].clone(), u.clone(), g.clone())
+        return fill
+
+    seq, pip = {}, {}
+    for s in range(nb):
+        make_fill(seq)(s, loop(s, 1))
+    torch.cuda.synchronize()
+    pipe = PhasedPipeline(loop, make_fill(pip), chains=2, max_loop_batches=2)          # rounds of 4, 3 steps: loops of 2+2 and 2+1 steps
+    assert [len(p) for _, p in pipe.plan(nb)] == [2, 2] and sum(n for _, p in pipe.plan(nb) for _, _, n in p) == nb
+    pipe.record_timeline = True
+    pipe.run(nb)
+    torch.cuda.synchronize()
+    assert set(seq) == set(pip) and len(pipe.timeline) == 2
+    for key in seq:
+        for a, b in zip(seq[key], pip[key]):
+            assert torch.equal(a, b), key
+    assert all(t["grids_done_ms"] >= t["loops_done_ms"] > 0 for t in pipe.timeline)

@@ -143,3 +143,21 @@ def test_decoder_state_key_sees_rebound_tensors():
     k2 = dec._state_key()
     dec.load_state_dict(sd, assign=True)
     assert dec._state_key() != k2
+
+
+def test_phased_pipeline_plan_covers_every_batch_once():
+    """parallel.PhasedPipeline.plan: rounds of at most chains x max_loop_batches batches, every batch in exactly one loop,
+    loops of a round balanced to within one batch, never an empty loop."""
+    from surfd_amd.parallel import PhasedPipeline
+    for chains, mx in [(1, 4), (2, 10), (2, 2), (3, 5)]:
+        pipe = PhasedPipeline(None, None, chains=chains, max_loop_batches=mx)
+        for n in list(range(1, 30)) + [40, 97]:
+            seen = []
+            for first, parts in pipe.plan(n):
+                sizes = [cnt for _, _, cnt in parts]
+                assert 1 <= len(parts) <= chains and min(sizes) >= 1 and max(sizes) <= mx and max(sizes) - min(sizes) <= 1
+                assert parts[0][1] == first and len({c for c, _, _ in parts}) == len(parts)
+                for _, f, cnt in parts:
+                    seen.extend(range(f, f + cnt))
+            assert seen == list(range(n)), (chains, mx, n)
+    assert PhasedPipeline(None, None, chains=2, max_loop_batches=10).plan(20) == [(0, [(0, 0, 10), (1, 10, 10)])]      # the driver command: one round
