@@ -263,3 +263,41 @@ def test_duplicate_and_component_invariants(mesh):
     k = max(sizes.values())
     kv, kf = mp.keep_components_with_at_least(v, f, k)
     assert len(kf) == sum(s for s in sizes.values() if s >= k)
+
+
+def _open_sheet(n=9, h=0.1):
+    """flat n x n vertex grid in the z = 0 plane, two triangles per cell"""
+    ii, jj = np.mgrid[0:n, 0:n]
+    v = np.stack([ii.ravel() * h, jj.ravel() * h, np.zeros(n * n)], 1).astype(np.float64)
+    idx = lambda i, j: i * n + j
+    f = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            f.append([idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)])
+            f.append([idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)])
+    return v, np.array(f, dtype=np.int64)
+
+
+def test_laplacian_smoothing_keeps_the_border_of_an_open_sheet():
+    """MeshLab's apply_coord_laplacian_smoothing defaults (boundary=True, cotangent weights) smooth border
+    vertices only along the border polyline.  On a flat open sheet: nothing leaves the plane, every non-corner border vertex
+    stays ON its border line and at its place (evenly spaced neighbours), only the four corners round off; with
+    boundary=False the border is pulled inwards (what the previous uniform umbrella did)."""
+    n, h = 9, 0.1
+    v, f = _open_sheet(n, h)
+    out = mp.laplacian_smooth(v, f, steps=3)
+    assert np.abs(out[:, 2]).max() == 0.0
+    side = (n - 1) * h
+    on_left = np.isclose(v[:, 0], 0.0) & (v[:, 1] > 1e-9) & (v[:, 1] < side - 1e-9)
+    far_from_corner = on_left & (v[:, 1] > 3.5 * h) & (v[:, 1] < side - 3.5 * h)
+    np.testing.assert_allclose(out[far_from_corner], v[far_from_corner], atol=1e-12)          # on the line x = 0, not moved along it
+    assert np.abs(out[on_left, 0]).max() < 0.2 * h                               # next to a rounded corner: dragged along by it, a little
+    corner = np.isclose(v[:, 0], 0.0) & np.isclose(v[:, 1], 0.0)
+    assert 0 < out[corner, 0][0] < h and 0 < out[corner, 1][0] < h                # corners round off, by less than a cell
+    interior = (v[:, 0] > 3.5 * h) & (v[:, 0] < side - 3.5 * h) & (v[:, 1] > 3.5 * h) & (v[:, 1] < side - 3.5 * h)
+    np.testing.assert_allclose(out[interior], v[interior], atol=1e-12)            # a regular interior is a fixed point
+    shrunk = mp.laplacian_smooth(v, f, steps=3, boundary=False)
+    assert shrunk[far_from_corner, 0].min() > 0.2 * h                             # without the border rule the whole hem creeps inwards
+    # uniform weights, border rule on: same fixed points
+    uni = mp.laplacian_smooth(v, f, steps=3, cotangent=False)
+    assert np.abs(uni[far_from_corner, 0]).max() < 1e-12
