@@ -152,13 +152,22 @@ def setup_dist(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    # SURFD_BENCH_BACKEND=gloo: development aid — runs the N > 1 code path (launcher, barriers, per-rank gather) with
+    # several ranks SHARING the GPUs that exist (RCCL refuses two ranks on one device); the number it prints is not a
+    # scaling measurement and says so
+    backend = os.environ.get("SURFD_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local % torch.cuda.device_count() if backend == "gloo" else local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")      # RCCL over xGMI
+        dist.init_process_group(backend=backend)      # nccl = RCCL over xGMI
     assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
     return world, rank, local
+
+
+def _host_if_gloo(t):
+    import torch.distributed as dist
+    return t.cpu() if dist.get_backend() == "gloo" else t
 
 
 def barrier(world):
@@ -514,14 +523,14 @@ def main():
         import torch.distributed as dist
         fwd_l, fwd_m = prof["dec_fwd"]; grd_l, grd_m = prof["dec_grad"]; lp_n, lp_m = prof["loop"]
         loops_done = max((m.get("loops_done_ms", 0.0) for m in timeline), default=0.0)
-        mine = torch.tensor([local_elapsed * 1e3, lp_m, fwd_m, grd_m, loops_done, fwd_total, float(os.cpu_count() or 0)],
-                            device="cuda", dtype=torch.float64)
+        mine = _host_if_gloo(torch.tensor([local_elapsed * 1e3, lp_m, fwd_m, grd_m, loops_done, fwd_total, float(os.cpu_count() or 0)],
+                                          device="cuda", dtype=torch.float64))
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "ms_per_step": float(v[0]) / a.steps, "loop_latency_ms_sum": float(v[1]), "decoder_fwd_ms": float(v[2]),
                      "decoder_fwd_bwd_ms": float(v[3]), "last_round_loops_done_ms": float(v[4]), "decoder_fwd_queries": float(v[5])}
                     for r, v in enumerate(allr)]
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = _host_if_gloo(torch.tensor([elapsed], device="cuda", dtype=torch.float64))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         from surfd_amd.parallel import gather_latents
@@ -575,6 +584,7 @@ def main():
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic (seeded random-init weights of the reference architectures, seeded noise" + (", seeded context vectors" if conditioned else "") + "; different shapes in every step)",
         "rccl_ranks": rccl_ranks,
+        **({"not_a_scaling_measurement": "SURFD_BENCH_BACKEND=gloo: the ranks share the GPUs of this box"} if os.environ.get("SURFD_BENCH_BACKEND") == "gloo" and world > 1 else {}),
         "config": {"workload": f"{cfg['name']}; {T}-step {'DDPM' if a.diffusion_steps == 1000 else 'DDIM'}, L={a.latent}, "
                                + (f"{N}^3 coarse-to-fine UDF grid + gradients, W-real: the synthetic decoder's own occupancy" if trace is None else
                                   f"W-trace: reverse loops + decoder over the {N}^3 thin-shell query lists of a trained-model-like field")
@@ -680,11 +690,11 @@ def grid_shard_main(a, world, rank):
     per_rank = None
     if world > 1:
         import torch.distributed as dist
-        mine = torch.tensor([local_ms], device="cuda", dtype=torch.float64)
+        mine = _host_if_gloo(torch.tensor([local_ms], device="cuda", dtype=torch.float64))
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "ms_per_step": float(v[0]) / a.steps} for r, v in enumerate(allr)]
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = _host_if_gloo(torch.tensor([elapsed], device="cuda", dtype=torch.float64))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank != 0:

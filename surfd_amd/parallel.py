@@ -50,11 +50,16 @@ def gather_latents(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
     world = dist.get_world_size()
     assert len(counts) == world
     m = max(counts)
-    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    # gloo moves host memory: device tensors take a round trip through the host there (CPU tests; a bench run whose ranks
+    # share one GPU); RCCL gathers device memory over xGMI
+    via_host = local.is_cuda and dist.get_backend() == "gloo"
+    work = local.cpu() if via_host else local
+    pad = torch.zeros((m,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+    pad[: work.shape[0]] = work
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    res = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    return res.to(local.device) if via_host else res
 
 
 def sample_sharded(diffusion, model, total: int, latent_len: int, sampler: str = "ddpm", seed: int = 1234,

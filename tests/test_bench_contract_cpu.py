@@ -89,5 +89,5 @@ def test_committed_traffic_is_what_the_tool_derives(tmp_path, bench):
         if isinstance(v, float):
             assert committed[k] == pytest.approx(v, rel=1e-12), k
     summary = json.load(open(src))
-    dec = [v for k, v in summary["fetch"].items() if "decoder_kernel<false, true>" in k][0]
+    dec = [v for k, v in summary["fetch"].items() if "decoder_fwd8_kernel" in k][0]
     assert committed["decoder_fwd_fetch_bytes_per_launch"] == pytest.approx(dec["FETCH_SIZE"] * 1024 * 2 / dec["dispatches"])

@@ -27,7 +27,8 @@ def pick(tag, sub):
 
 WEIGHT_BYTES = 553_294_340          # fp16 planes streamed per denoiser evaluation (bench.py: algorithmic_bytes_per_evaluation)
 CONVS_PER_EVAL = 84
-dec_f, dec_w, dec_s = (pick(t, "decoder_kernel<false, true>") for t in ("fetch", "write", "sq"))
+FWD = "decoder_fwd8_kernel" if any("decoder_fwd8_kernel" in k for k in r.get("fetch", {})) else "decoder_kernel<false, true>"   # the default forward kernel of the round
+dec_f, dec_w, dec_s = (pick(t, FWD) for t in ("fetch", "write", "sq"))
 n_dec = max(dec_f["dispatches"], 1)
 unet_fetch = sum(pick("fetch", k).get("FETCH_SIZE", 0) for k in ("conv2_kernel", "attn_kernel")) * 1024 * 2
 unet_write = sum(pick("write", k).get("WRITE_SIZE", 0) for k in ("conv2_kernel", "attn_kernel")) * 1024
@@ -38,6 +39,7 @@ out = {
                "--warmup 0 --diffusion-steps 20 ...` (the shortened command of tools/profile_round.sh: same kernels and grid shapes as the "
                "headline run, whose full length under --pmc would be hundreds of thousands of serialised dispatches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
                "64 B); counters sit on the L2's fabric side and include Infinity-Cache hits"),
+    "decoder_fwd_kernel": FWD,
     "decoder_fwd_launches_measured": n_dec,
     "decoder_fwd_fetch_bytes_per_launch": dec_f.get("FETCH_SIZE", 0) * 1024 * 2 / n_dec,
     "decoder_fwd_write_bytes_per_launch": dec_w.get("WRITE_SIZE", 0) * 1024 / n_dec,
@@ -51,7 +53,9 @@ out["unet_fetch_over_algorithmic"] = out["unet_eval_fetch_bytes"] / WEIGHT_BYTES
 for name, d in (("decoder_fwd", dec_s), ("decoder_grad", pick("sq", "decoder_kernel<true, true>")), ("conv2", c2)):
     wc = d.get("SQ_WAVE_CYCLES", 0)
     if wc:
-        out[name + "_mfma_busy_frac"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * wc)
+        # SQ_WAVE_CYCLES sums over resident waves (quad-cycles): a kernel with two waves per SIMD counts every SIMD cycle twice
+        per_simd = 2 if (name == "decoder_fwd" and FWD == "decoder_fwd8_kernel") else 1
+        out[name + "_mfma_busy_frac"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * wc / per_simd)
         out[name + "_valu_frac"] = d.get("SQ_ACTIVE_INST_VALU", 0) / wc
         out[name + "_wait_frac"] = d.get("SQ_WAIT_ANY", 0) / wc
 json.dump(out, open(dst, "w"), indent=1)
