@@ -396,8 +396,9 @@ def main():
     chains = [model] + [model.replica() for _ in range(n_chains - 1)]
     for m in chains[1:]:
         m.set_precision(a.unet_precision)
-    # a conditioned loop keeps one embedding row per (iteration, latent): 56 KB x T x latents -> narrower loops
-    loop_batches = a.loop_batches if not conditioned else max(1, min(a.loop_batches, 16 // max(1, B // 8)))
+    # (a conditioned loop keeps one embedding row per (iteration, latent) in HBM: 56 KB x T x latents = 4.5 GB for an
+    # 80-wide loop — sized for 288 GB, not for a 16 GB card)
+    loop_batches = a.loop_batches
     if a.schedule == "phased":
         for m in chains:
             m.set_wide(a.wide_design_batch)
@@ -503,6 +504,9 @@ def main():
         grad_total = float(sum(c.shape[0] for k, c in trace if k == "grad")) * B * a.steps
     n_fwd, n_grad = fwd_total / (B * a.steps), grad_total / (B * a.steps)
     mesh_stats = mesher.stats() if mesher is not None else None
+    if mesher is not None:
+        mesher.close()
+        mesher = None
     # ---- untimed extras: one loop alone at the widest batch the schedule used --------------------------------------
     dec.set_grid_blocks(0)
     if a.schedule == "overlap" and a.loop_cus != 256:
@@ -541,8 +545,6 @@ def main():
     w_trace = None
     if not a.no_trace:
         del udf, grads
-        if mesher is not None:
-            mesher.close()
         torch.cuda.empty_cache()
         w_trace = time_trace(dec, lat, trace if trace is not None else make_trace(N))
     shapes = world * B * a.steps

@@ -586,3 +586,26 @@ def test_phased_pipeline_matches_sequential(wide_model):
         for a, b in zip(seq[key], pip[key]):
             assert torch.equal(a, b), key
     assert all(t["grids_done_ms"] >= t["loops_done_ms"] > 0 for t in pipe.timeline)
+
+
+def test_wide_form_conditioned_latent_does_not_depend_on_batch_width():
+    """The same contract with per-sample conditioning (configs C4 / C5: a 512-d context row per latent, L = 64): a short
+    conditioned DDIM loop over 12 latents equals, bit for bit, the loops over 5 + 7 of them, and the forward of a sub-batch
+    equals the rows of the full batch (the embedding Linears chunk their rows and K axis independently of B in this form)."""
+    model, _, _ = _model("img")
+    _, dd, _ = _model("no_cond", "ddim10")
+    model.set_wide(32)
+    try:
+        L = 64
+        ctx = synth.synth_context(300, 12).cuda()
+        run = lambda first, n: dd.ddim_sample_loop(model, (n, 1, L), clip_denoised=False, model_kwargs={"y": {"context": ctx[first:first + n].contiguous()}},
+                                                   noise_stream=synth.synth_noise_batch(10, 300 + first, n, L).cuda(), fused=True).clone()
+        whole = run(0, 12)
+        assert torch.equal(run(0, 5), whole[:5]) and torch.equal(run(5, 7), whole[5:])
+        x = torch.randn(12, 1, L, generator=torch.Generator().manual_seed(9)).cuda()
+        t = torch.randint(0, 1000, (12,), generator=torch.Generator().manual_seed(10)).cuda()
+        full = model(x, t, y={"context": ctx}).clone()
+        part = model(x[3:6].contiguous(), t[3:6].contiguous(), y={"context": ctx[3:6].contiguous()})
+        assert torch.equal(part, full[3:6])
+    finally:
+        model.set_wide(0)
