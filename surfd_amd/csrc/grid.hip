@@ -30,22 +30,54 @@ constexpr int CTR_FAR = SURFD_GRID_MAX_LEVELS;      // [8..15]  far blocks found
 constexpr int CTR_GRAD = 2 * SURFD_GRID_MAX_LEVELS; // [16]     gradient points
 constexpr int CTR_TOTAL = CTR_GRAD + 1;
 
-__global__ void classify_kernel(PtIO io, const float *udf, float thr, int *close_list, int *close_count,
-                                int *far_list, int *far_count) {
+// Appends are aggregated per WORKGROUP and per four elements a thread: one pair of atomics reserves the slots of 1024
+// elements (one atomic per wave serialised at ~11 ns each — 150 000 waves x 2 lists = 3.3 of the 4.0 ms this kernel took
+// on the largest level; the decoder launches of the next level wait for it).
+__global__ __launch_bounds__(256) void classify_kernel(PtIO io, const float *udf, float thr, int *close_list, int *close_count,
+                                                       int *far_list, int *far_count) {
+    constexpr int ITEMS = 4;
+    __shared__ int wcnt[2][4], wbase[2][4];
     const long n = pt_count(io);
-    for (long e0 = blockIdx.x * (long)blockDim.x; e0 < n; e0 += (long)gridDim.x * blockDim.x) {
-        const long e = e0 + threadIdx.x;
-        const bool valid = e < n;
-        int idx = 0;
-        bool close = false;
-        if (valid) {
-            idx = pt_voxel(io, e);
-            close = fabsf(udf[idx]) < thr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long e0 = blockIdx.x * (long)(blockDim.x * ITEMS); e0 < n; e0 += (long)gridDim.x * blockDim.x * ITEMS) {
+        int idx[ITEMS];
+        bool cl[ITEMS], fr[ITEMS];
+        int ncl = 0, nfr = 0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const long e = e0 + (long)i * blockDim.x + threadIdx.x;
+            idx[i] = 0; cl[i] = fr[i] = false;
+            if (e < n) {
+                idx[i] = pt_voxel(io, e);
+                cl[i] = fabsf(udf[idx[i]]) < thr;
+                fr[i] = !cl[i];
+            }
+            ncl += cl[i]; nfr += fr[i];
         }
-        const int sc = wave_append_slot(close_count, valid && close);
-        if (sc >= 0) close_list[sc] = idx;
-        const int sf = wave_append_slot(far_count, valid && !close);
-        if (sf >= 0) far_list[sf] = idx;
+        // exclusive prefix of the per-lane counts inside the wave, wave totals through LDS, one reservation per list
+        int pcl = ncl, pfr = nfr;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int a = __shfl_up(pcl, off), b = __shfl_up(pfr, off);
+            if (lane >= off) { pcl += a; pfr += b; }
+        }
+        if (lane == 63) { wcnt[0][wave] = pcl; wcnt[1][wave] = pfr; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int l = threadIdx.x;
+            const int tot = wcnt[l][0] + wcnt[l][1] + wcnt[l][2] + wcnt[l][3];
+            int base = tot ? atomicAdd(l ? far_count : close_count, tot) : 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { wbase[l][w] = base; base += wcnt[l][w]; }
+        }
+        __syncthreads();
+        int sc = wbase[0][wave] + pcl - ncl, sf = wbase[1][wave] + pfr - nfr;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (cl[i]) close_list[sc++] = idx[i];
+            if (fr[i]) far_list[sf++] = idx[i];
+        }
+        __syncthreads();          // wcnt / wbase are rewritten by the next iteration
     }
 }
 
@@ -111,6 +143,56 @@ __global__ void grad_commit_kernel(const int *list, long n, const float *ng, flo
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const long idx = list[e];
         grads[idx * 3 + 0] = ng[e * 3 + 0]; grads[idx * 3 + 1] = ng[e * 3 + 1]; grads[idx * 3 + 2] = ng[e * 3 + 2];
+    }
+}
+
+// Ordered stream compaction of a voxel predicate over [0, n): out[] = the indices with pred(i), ascending; *count = how many.
+// Wave w owns the contiguous range [w * SEL_SPAN, (w + 1) * SEL_SPAN): pass 1 counts, a single workgroup scans the wave
+// counts, pass 2 writes with ballot prefixes (no workgroup barrier in either loop).  Two coalesced reads of the predicate's
+// input instead of a general-purpose device-wide partition (1.4 ms per 512^3 volume -> the 0.3 ms two reads of 512 MB cost).
+constexpr int SEL_SPAN = 16384;
+template <class Pred>
+__global__ __launch_bounds__(256) void select_count_kernel(Pred pred, long n, int *wave_counts) {
+    const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long lo = w * SEL_SPAN, hi = min(n, lo + SEL_SPAN);
+    int c = 0;
+    for (long e = lo + lane; e < hi; e += 64) c += pred((int)e) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0 && lo < n) wave_counts[w] = c;
+}
+// exclusive scan of `m` wave counts in place (m <= 16384), total -> *count
+__global__ __launch_bounds__(1024) void select_scan_kernel(int *wave_counts, int m, int *count) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (m + 1023) / 1024;
+    int s = 0;
+    for (int i = 0; i < per; ++i) { const int k = t * per + i; if (k < m) s += wave_counts[k]; }
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = 0; i < per; ++i) { const int k = t * per + i; if (k < m) { const int c = wave_counts[k]; wave_counts[k] = run; run += c; } }
+    if (t == 1023) *count = part[1023];
+}
+template <class Pred>
+__global__ __launch_bounds__(256) void select_write_kernel(Pred pred, long n, const int *wave_offsets, int *out) {
+    const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long lo = w * SEL_SPAN, hi = min(n, lo + SEL_SPAN);
+    if (lo >= n) return;
+    int off = wave_offsets[w];
+    for (long e0 = lo; e0 < hi; e0 += 64) {
+        const long e = e0 + lane;
+        const bool p = e < hi && pred((int)e);
+        const unsigned long long m = __ballot(p);
+        if (p) out[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)e;
+        off += __popcll(m);
     }
 }
 
@@ -181,12 +263,22 @@ struct BelowThreshold {
     __device__ __forceinline__ bool operator()(const int &i) const { return udf[i] < thr; }
 };
 
-static int compact_grad_list(surfd_grid *g, const float *udf, float thr, hipStream_t st) {
-    const int N3 = g->N * g->N * g->N;
-    hipcub::CountingInputIterator<int> idx(0);
-    size_t bytes = g->sel_tmp_bytes;
-    HIP_TRY(hipcub::DeviceSelect::If(g->sel_tmp, bytes, idx, g->grad_list, g->counters + CTR_GRAD, N3, BelowThreshold{udf, thr}, st));
+template <class Pred>
+static int ordered_select(Pred pred, long n, int *wave_tmp, int *out, int *count, hipStream_t st) {
+    const int m = (int)ceil_div<long>(n, SEL_SPAN);
+    const unsigned blocks = (unsigned)ceil_div(m, 4);
+    hipLaunchKernelGGL((select_count_kernel<Pred>), dim3(blocks), dim3(256), 0, st, pred, n, wave_tmp);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, st, wave_tmp, m, count);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL((select_write_kernel<Pred>), dim3(blocks), dim3(256), 0, st, pred, n, (const int *)wave_tmp, out);
+    LAUNCH_CHECK();
     return SURFD_OK;
+}
+
+static int compact_grad_list(surfd_grid *g, const float *udf, float thr, hipStream_t st) {
+    const long N3 = (long)g->N * g->N * g->N;
+    return ordered_select(BelowThreshold{udf, thr}, N3, (int *)g->sel_tmp, g->grad_list, g->counters + CTR_GRAD, st);
 }
 
 static int grid_alloc(surfd_grid *g) {
@@ -200,11 +292,8 @@ static int grid_alloc(surfd_grid *g) {
     const long far_cap = nl >= 2 ? (long)g->levels[nl - 2] * g->levels[nl - 2] * g->levels[nl - 2] : 1;
     HIP_TRY(hipMalloc((void **)&g->far_list, far_cap * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->grad_list, N3 * sizeof(int)));
-    {
-        hipcub::CountingInputIterator<int> idx(0);
-        HIP_TRY(hipcub::DeviceSelect::If(nullptr, g->sel_tmp_bytes, idx, g->grad_list, g->counters, (int)N3, BelowThreshold{nullptr, 0.f}, nullptr));
-        HIP_TRY(hipMalloc(&g->sel_tmp, g->sel_tmp_bytes));
-    }
+    g->sel_tmp_bytes = (size_t)ceil_div<long>(N3, SEL_SPAN) * sizeof(int);      // wave counts / offsets of the ordered compaction
+    HIP_TRY(hipMalloc(&g->sel_tmp, g->sel_tmp_bytes));
     HIP_TRY(hipMalloc((void **)&g->counters, CTR_TOTAL * sizeof(int)));
     HIP_TRY(hipMemset(g->counters, 0, CTR_TOTAL * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->totals, (SURFD_GRID_MAX_LEVELS + 2) * sizeof(unsigned long long)));
@@ -481,8 +570,7 @@ int surfd_band_create(int N, int64_t capacity, surfd_band **out) {
     HIP_TRY(hipMalloc((void **)&b->idx, (size_t)N3 * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&b->count, sizeof(int)));
     HIP_TRY(hipMalloc((void **)&b->packed, (size_t)capacity * 4 * sizeof(float)));
-    hipcub::CountingInputIterator<int> it(0);
-    HIP_TRY(hipcub::DeviceSelect::If(nullptr, b->tmp_bytes, it, b->idx, b->count, N3, InBand{nullptr, 0.f}, nullptr));
+    b->tmp_bytes = (size_t)ceil_div<long>(N3, SEL_SPAN) * sizeof(int);
     HIP_TRY(hipMalloc(&b->tmp, b->tmp_bytes));
     HIP_TRY(hipHostMalloc((void **)&b->h_idx, (size_t)capacity * sizeof(int), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&b->h_packed, (size_t)capacity * 4 * sizeof(float), hipHostMallocDefault));
@@ -508,10 +596,9 @@ void surfd_band_destroy(surfd_band *b) {
 int surfd_band_compact(surfd_band *b, const float *udf, const float *grads, float max_thr, surfd_stream s) {
     if (!b || !udf || !grads) SURFD_FAIL(SURFD_ERR_ARG, "surfd_band_compact: null argument");
     hipStream_t st = as_stream(s);
-    const int N3 = b->N * b->N * b->N;
-    hipcub::CountingInputIterator<int> it(0);
-    size_t bytes = b->tmp_bytes;
-    HIP_TRY(hipcub::DeviceSelect::If(b->tmp, bytes, it, b->idx, b->count, N3, InBand{udf, max_thr}, st));
+    const long N3 = (long)b->N * b->N * b->N;
+    int rc = ordered_select(InBand{udf, max_thr}, N3, (int *)b->tmp, b->idx, b->count, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(band_gather_kernel, dim3(1024), dim3(256), 0, st, (const int *)b->idx, (const int *)b->count, b->cap, udf, grads, b->packed);
     LAUNCH_CHECK();
     HIP_TRY(hipEventRecord(b->ready, st));
