@@ -185,9 +185,6 @@ typedef f16x8 __attribute__((address_space(1))) gf16x8;
 #ifndef SURFD_DEC_MIX
 #define SURFD_DEC_MIX 1
 #endif
-#ifndef SURFD_DEC_PKFMA
-#define SURFD_DEC_PKFMA 0
-#endif
 __device__ __forceinline__ unsigned split_low_pair(unsigned h, float u0, float u1) {
 #if SURFD_DEC_MIX
     unsigned l;
@@ -1243,27 +1240,6 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     // X <- split(min(relu(a*v + b), 65504)) for this wave's 64 channels x 64 points
     auto store8 = [&](const f32x16 (&v)[2][2], const float (&sa)[2], const float (&sb)[2]) {
         float umax = 0.f;
-#if SURFD_DEC_PKFMA
-        // the affine map on two adjacent accumulator registers (= two points of one channel) at a time: one packed FMA
-        const f32x2 a0 = {sa[0], sa[0]}, a1 = {sa[1], sa[1]}, b0 = {sb[0], sb[0]}, b1 = {sb[1], sb[1]};
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 v0 = {v[mt][0][r], v[mt][0][r + 1]}, v1 = {v[mt][1][r], v[mt][1][r + 1]};
-                const f32x2 t0 = __builtin_elementwise_fma(a0, v0, b0), t1 = __builtin_elementwise_fma(a1, v1, b1);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0[i], t1[i]));
-                    const float u0 = __builtin_amdgcn_fmed3f(t0[i], 0.f, 65504.f);
-                    const float u1 = __builtin_amdgcn_fmed3f(t1[i], 0.f, 65504.f);
-                    const f32x2 u = {u0, u1};
-                    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(u, f16x2));
-                    XW8(mt, r + i, 0) = h;
-                    XW8(mt, r + i, 1) = split_low_pair(h, u0, u1);
-                }
-            }
-#else
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1278,7 +1254,6 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
                 XW8(mt, r, 0) = h;
                 XW8(mt, r, 1) = split_low_pair(h, u0, u1);
             }
-#endif
         sat_flag |= __any(umax > 65504.f);
     };
     auto zero8 = [](f32x16 (&a)[2][2]) {
