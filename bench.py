@@ -84,6 +84,10 @@ def parse():
                     help="phased: steps whose latents ride in ONE wide reverse loop (10 x 8 = 80 latents per loop)")
     ap.add_argument("--wide-design-batch", type=int, default=32,
                     help="phased: design batch of the conv kernel's wide form (MDM.set_wide); the K split, hence the bits, depend on it, not on the loop width")
+    ap.add_argument("--overlap-blocks", type=int, default=0,
+                    help="phased: 0 = time-sliced rounds; D > 0 = the loops of round r + 1 run next to the grids of round r, which then "
+                         "use D persistent decoder workgroups (the chip is power-bound under the decoder: 192 CUs deliver 94 %% of 256)")
+    ap.add_argument("--first-round", type=int, default=0, help="phased with --overlap-blocks: steps in the first round (its loops run alone)")
     ap.add_argument("--decoder-blocks", type=int, default=192,
                     help="overlap: persistent decoder workgroups per launch while loops run on the remaining CUs")
     ap.add_argument("--loop-cus", type=int, default=64,
@@ -442,7 +446,8 @@ def main():
                 mesher.submit(udf[k], grads[k], tag=(step, k))     # device-side band compaction + async D2H; meshing on host threads
 
     if a.schedule == "phased":
-        pipe = PhasedPipeline(sample_latents, fill_grids, chains=n_chains, max_loop_batches=loop_batches)
+        pipe = PhasedPipeline(sample_latents, fill_grids, chains=n_chains, max_loop_batches=loop_batches, overlap_blocks=a.overlap_blocks,
+                              decoder=dec, first_round_batches=a.first_round if a.overlap_blocks else 0)
     elif a.schedule == "overlap":
         pipe = BatchPipeline(dec, lambda s, q: sample_latents(s, 1, q), fill_grids, a.decoder_blocks, loop_chains=n_chains)
     else:
@@ -566,7 +571,9 @@ def main():
     unet_peak = F16_MFMA_PEAK_TF / 3.0 if a.unet_precision == "f16x2" else FP32_MFMA_PEAK_TF      # algorithmic flops / s
     roof_eval_us = max(UNET_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e9), flops_eval / (unet_peak * 1e12)) * 1e6
     # time the loops had the chip: phased = up to the last loop of each round; otherwise they overlap the grids
-    if a.schedule == "phased" and timeline:
+    if a.schedule == "phased" and timeline and a.overlap_blocks:
+        loop_phase_ms = timeline[0]["loops_done_ms"]         # only the first round's loops have the chip to themselves
+    elif a.schedule == "phased" and timeline:
         prev, loop_phase_ms = 0.0, 0.0
         for m in timeline:
             loop_phase_ms += m["loops_done_ms"] - prev
@@ -574,7 +581,13 @@ def main():
     else:
         loop_phase_ms = None
     streamed_gbs = loops * T * UNET_WEIGHT_BYTES / ((loop_phase_ms * 1e-3) if loop_phase_ms else elapsed) / 1e9
-    sched = {"phased": (f"time-sliced rounds: the reverse loops of up to {n_chains} x {loop_batches} steps as {n_chains} wide loops at once (conv kernel in "
+    if a.schedule == "phased" and a.overlap_blocks:
+        phased_txt = (f"overlapped rounds: the reverse loops of round r + 1 ({n_chains} wide loops at once, up to {loop_batches} steps each, conv kernel in its wide "
+                      f"form) run next to the grids of round r on {a.overlap_blocks} persistent decoder workgroups (first round of {a.first_round or 'equal'} steps: its loops "
+                      "run alone; last round's grids: all CUs); every step runs start to finish inside the timed region")
+    else:
+        phased_txt = None
+    sched = {"phased": phased_txt or (f"time-sliced rounds: the reverse loops of up to {n_chains} x {loop_batches} steps as {n_chains} wide loops at once (conv kernel in "
                         f"its wide form, K split designed for {a.wide_design_batch} latents), the whole chip theirs, then the round's grids with the decoder's "
                         "persistent workgroups on every CU; every step runs start to finish inside the timed region"),
              "overlap": (f"{n_chains} reverse loops of different steps in flight (own stream + context each, split-K sized for {a.loop_cus} CUs) next to the grids "

@@ -227,13 +227,18 @@ class BatchPipeline:
 
 
 class PhasedPipeline:
-    """Time-sliced schedule over independent batches on ONE GPU: all reverse loops of a ROUND of batches first — as
-    `chains` wide loops at once (each over several batches' latents: the denoiser's weights are streamed once per
-    evaluation for all of them; conv kernel in its wide form, `MDM.set_wide`), the whole chip theirs — then the grids of
-    the round, the decoder's persistent workgroups on every CU.  Neither stage has to share CUs with the other: the
-    decoder (512 registers per lane, one workgroup per CU) cannot co-reside with anything, and a loop squeezed onto a
-    quarter of the chip pays for it in workgroup slots (measured, profiles/r03_loop_batch.md).  A shape's result does
-    not depend on the round or the loop it rode in (tests/test_gpu_unet.py).
+    """Schedule over independent batches on ONE GPU in ROUNDS: the reverse loops of a round of batches as `chains` wide loops
+    at once (each over several batches' latents: the denoiser's weights are streamed once per evaluation for all of them;
+    conv kernel in its wide form, `MDM.set_wide`), then the grids of the round.
+
+    Time-sliced (overlap_blocks = 0, the default): a round's loops have the whole chip, then its grids have it — the
+    decoder kernels (all registers of a CU) cannot co-reside with anything.
+    Overlapped (overlap_blocks = D > 0, needs `decoder`): the loops of round r + 1 run NEXT TO the grids of round r, which
+    then use D persistent decoder workgroups (the last round's grids all CUs).  Under the decoder kernel the chip is
+    power-bound (profiles/r03_decoder_variants.md: 256 CUs sustain 1.70 GHz, 192 CUs 6 % less throughput, not 25 %), so
+    the CUs lent to the latency-bound loops cost little; only the first round's loops run alone (`first_round_batches`).
+
+    A shape's result does not depend on the round, the loop or the schedule it rode in (tests/test_gpu_unet.py).
 
         pipe = PhasedPipeline(loop_fn, fill_fn, chains=2, max_loop_batches=8)
         pipe.run(n_batches)
@@ -243,22 +248,34 @@ class PhasedPipeline:
     fill_fn(batch, latents_of_batch) -> None  enqueues that batch's grid evaluation on the current stream
     """
 
-    def __init__(self, loop_fn, fill_fn, chains: int = 2, max_loop_batches: int = 8):
+    def __init__(self, loop_fn, fill_fn, chains: int = 2, max_loop_batches: int = 8, overlap_blocks: int = 0, decoder=None,
+                 first_round_batches: int = 0):
         self.loop_fn, self.fill_fn = loop_fn, fill_fn
         self.chains = max(1, int(chains))
         self.max_loop_batches = max(1, int(max_loop_batches))
+        self.overlap_blocks = int(overlap_blocks)
+        self.decoder = decoder
+        if self.overlap_blocks and decoder is None:
+            raise ValueError("PhasedPipeline(overlap_blocks=...) needs the decoder whose launches it sizes")
+        self.first_round_batches = int(first_round_batches)
         self.loop_streams = None                 # created on first run (plan() needs no device)
         self.record_timeline = False
         self.timeline = []
 
     def plan(self, n_batches: int):
-        """[(first_batch, [(chain, first, count), ...]), ...]: rounds of at most chains * max_loop_batches batches, the
-        batches of the job spread evenly over the rounds and a round's batches evenly over the chains."""
+        """[(first_batch, [(chain, first, count), ...]), ...]: rounds of at most chains * max_loop_batches batches — an
+        optional smaller first round (overlapped schedule: its loops run alone), the rest spread evenly over the remaining
+        rounds — and a round's batches spread evenly over the chains."""
         per_round = self.chains * self.max_loop_batches
-        n_rounds = max(1, -(-n_batches // per_round))
-        rounds = []
-        for r in range(n_rounds):
-            first, count = shard_range(n_batches, n_rounds, r)
+        sizes = []
+        rest = n_batches
+        if self.first_round_batches and n_batches > self.first_round_batches:
+            sizes.append(min(self.first_round_batches, per_round))
+            rest -= sizes[0]
+        n_rounds = max(1, -(-rest // per_round))
+        sizes += [shard_range(rest, n_rounds, r)[1] for r in range(n_rounds)]
+        rounds, first = [], 0
+        for count in sizes:
             q = min(self.chains, count)
             parts = []
             for c in range(q):
@@ -266,6 +283,7 @@ class PhasedPipeline:
                 if n:
                     parts.append((c, first + f, n))
             rounds.append((first, parts))
+            first += count
         return rounds
 
     def run(self, n_batches: int) -> None:
@@ -276,13 +294,18 @@ class PhasedPipeline:
             self.loop_streams = [torch.cuda.Stream() for _ in range(self.chains)]
         cur = torch.cuda.current_stream()
         dev = torch.cuda.current_device()
+        overlap = self.overlap_blocks > 0
         t_begin = None
         if self.record_timeline:
             self.timeline = []
             t_begin = torch.cuda.Event(enable_timing=True)
             t_begin.record(cur)
         marks = []
-        for first, parts in self.plan(n_batches):
+        for st in self.loop_streams:
+            st.wait_stream(cur)                             # whatever the caller enqueued before (noise, weights)
+
+        def start_round(parts):
+            """one host thread per loop (a loop call blocks its caller while the device queue is full)"""
             results, errors = {}, []
 
             def worker(c, f, n):
@@ -290,7 +313,8 @@ class PhasedPipeline:
                     torch.cuda.set_device(dev)
                     st = self.loop_streams[c]
                     with torch.cuda.stream(st):
-                        st.wait_stream(cur)                 # the previous round's grids are done before this round's loops start
+                        if not overlap:
+                            st.wait_stream(cur)             # time-sliced: the previous round's grids are done before these loops start
                         x = self.loop_fn(f, n, c)
                         x.record_stream(cur)
                         ev = torch.cuda.Event(enable_timing=self.record_timeline)
@@ -299,26 +323,47 @@ class PhasedPipeline:
                 except BaseException as e:                  # surfaced on the calling thread
                     errors.append(e)
 
-            # one host thread per loop: a loop call blocks its caller while the device queue is full
-            threads = [threading.Thread(target=worker, args=p, daemon=True) for p in parts[1:]]
+            threads = [threading.Thread(target=worker, args=p, daemon=True) for p in parts]
             for t in threads:
                 t.start()
-            worker(*parts[0])
-            for t in threads:
-                t.join()
-            if errors:
-                raise errors[0]
-            for c, _, _ in parts:
-                cur.wait_event(results[c][3])
-            for c, _, _ in parts:
-                f, n, x, ev = results[c]
-                per = x.shape[0] // n
-                for b in range(n):
-                    self.fill_fn(f + b, x[b * per:(b + 1) * per])
-            if self.record_timeline:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record(cur)
-                marks.append((first, [results[c][3] for c, _, _ in parts], e1, sum(n for _, _, n in parts)))
+            return threads, results, errors
+
+        plan = self.plan(n_batches)
+        pending = start_round(plan[0][1])
+        try:
+            for r, (first, parts) in enumerate(plan):
+                threads, results, errors = pending
+                for t in threads:
+                    t.join()
+                if errors:
+                    raise errors[0]
+                nxt = None
+                if overlap and r + 1 < len(plan):
+                    nxt = start_round(plan[r + 1][1])       # the next round's loops go next to this round's grids
+                for c, _, _ in parts:
+                    cur.wait_event(results[c][3])
+                if overlap:
+                    self.decoder.set_grid_blocks(self.overlap_blocks if nxt is not None else 0)
+                for c, _, _ in parts:
+                    f, n, x, ev = results[c]
+                    per = x.shape[0] // n
+                    for b in range(n):
+                        self.fill_fn(f + b, x[b * per:(b + 1) * per])
+                if self.record_timeline:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(cur)
+                    marks.append((first, [results[c][3] for c, _, _ in parts], e1, sum(n for _, _, n in parts)))
+                if not overlap and r + 1 < len(plan):
+                    nxt = start_round(plan[r + 1][1])       # (their streams wait for this round's grids)
+                pending = nxt
+        finally:
+            if pending is not None:
+                for t in pending[0]:
+                    t.join()
+            if overlap:
+                self.decoder.set_grid_blocks(0)
+            for st in self.loop_streams:
+                cur.wait_stream(st)
         if self.record_timeline:
             torch.cuda.synchronize()
             self.timeline = [{"first_batch": f, "batches": nb, "loops_done_ms": max(t_begin.elapsed_time(e) for e in evs),

@@ -586,6 +586,18 @@ def test_phased_pipeline_matches_sequential(wide_model):
         for a, b in zip(seq[key], pip[key]):
             assert torch.equal(a, b), key
     assert all(t["grids_done_ms"] >= t["loops_done_ms"] > 0 for t in pipe.timeline)
+    # the overlapped variant (next round's loops beside this round's grids on part of the CUs, smaller first round): same bits
+    ovl = {}
+    pipe = PhasedPipeline(loop, make_fill(ovl), chains=2, max_loop_batches=2, overlap_blocks=96, decoder=dec, first_round_batches=1)
+    assert [sum(n for _, _, n in p) for _, p in pipe.plan(nb)] == [1, 3, 3]
+    pipe.run(nb)
+    torch.cuda.synchronize()
+    assert set(ovl) == set(seq)
+    for key in seq:
+        for a, b in zip(seq[key], ovl[key]):
+            assert torch.equal(a, b), key
+    with pytest.raises(ValueError):
+        PhasedPipeline(loop, make_fill({}), overlap_blocks=96)                    # needs the decoder it sizes
 
 
 def test_wide_form_conditioned_latent_does_not_depend_on_batch_width():
