@@ -100,7 +100,8 @@ def bench_e2(resolution: int, e1_shapes_per_s: float, threads: int = 8) -> dict:
     stage is measured on one thin-shell field of the benchmark's resolution (the occupancy of a trained model:
     222 793 vertices at 512^3): seconds per shape on one core, and the rate of `threads` independent shapes meshed
     concurrently (one per host core; ctypes releases the GIL).  In a pipelined service the host stage overlaps the GPU
-    work on later batches, so E2 = min(E1, host rate)."""
+    work on later batches.  These are STAGE figures for the line of an E1 run; the end-to-end rate through the meshes is
+    measured, not composed: `bench.py --endpoint e2` (BandMesher below)."""
     import os
     import time
     from concurrent.futures import ThreadPoolExecutor
@@ -141,12 +142,13 @@ def bench_e2(resolution: int, e1_shapes_per_s: float, threads: int = 8) -> dict:
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(lambda _: _run(u, g, 1), range(threads)))
     par_rate = threads / (time.perf_counter() - t0)
-    return {"status": "measured", "field": f"thin shell, {resolution}^3 ({len(v)} vertices / {len(f)} faces)",
-            "d2h_s_per_shape": d2h_s, "mc_s_per_shape_one_core": one_s, "mc_threads": threads,
+    return {"status": "stage figures, measured on the side of an E1 run — NOT an end-to-end rate; the timed end point is `bench.py --endpoint e2` "
+                      "(every mesh finished inside the timed region)",
+            "field": f"thin shell, {resolution}^3 ({len(v)} vertices / {len(f)} faces)",
+            "dense_d2h_s_per_shape": d2h_s, "mc_s_per_shape_one_core_dense_input": one_s, "mc_threads": threads,
             "mc_shapes_per_s": par_rate, "e1_shapes_per_s": e1_shapes_per_s,
-            "value": min(e1_shapes_per_s, par_rate), "unit": "shapes/s",
-            "note": "host stage (pageable D2H + native marching cubes, one shape per core) overlapped with the GPU work of later "
-                    "batches; reference marching cubes: 10.6 s per shape at 512^3 on one core (BASELINE.md)"}
+            "note": "pageable whole-volume D2H (what the reference does, meshudf.py:344-349; the timed path copies the near-surface band "
+                    "instead) + native marching cubes, one shape per core; reference marching cubes: 10.6 s per shape at 512^3 on one core (BASELINE.md)"}
 
 
 # ---- sparse hand-off: the mesher on the near-surface band only (csrc/mcubes.cpp: surfd_mc_udf_band) -------------------------
