@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03prof; mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-trace --no-e2 > $O/bench_under_rocprof.json 2> $O/kt.log
-SHORT="python bench.py --steps 4 --warmup 0 --diffusion-steps 20 --no-cpu-baseline --no-trace --no-e2"
+SHORT="python bench.py --steps 20 --warmup 0 --diffusion-steps 20 --no-cpu-baseline --no-trace --no-e2"      # the driver's 20 steps (loops of 80 latents, all grids), 20 instead of 1000 loop iterations
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- $SHORT > $O/pmc_fetch.json 2> $O/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- $SHORT > $O/pmc_write.json 2> $O/pmc_write.log
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o s -- $SHORT > $O/pmc_sq.json 2> $O/pmc_sq.log
