@@ -1,5 +1,6 @@
 """Developer aid: phase breakdown (us) of every f16x2 conv launch of one denoiser evaluation (workgroup 0).
-Needs a stamps build:  SURFD_EXTRA_HIPCC_FLAGS=-DSURFD_C2_STAMPS python surfd_amd/build.py --force ; run with SURFD_CONV_DEBUG=1."""
+python tools/debug_conv2_phases.py [B] [wide design batch].  Needs a stamps build (python tools/build_variants.py
+stamps=conv_f16x2.hip:-DSURFD_C2_STAMPS, selected with SURFD_LIB=...); run with SURFD_CONV_DEBUG=1."""
 import ctypes as C, os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +9,10 @@ from surfd_amd.mdm import create_model_and_diffusion, load_model_wo_clip
 args = types.SimpleNamespace(cond_mode="no_cond", arch="OpenUNet", num_actions=9, dataset="d", noise_schedule="cosine", sigma_small=True, clip_value=1.0)
 model, _ = create_model_and_diffusion(args)
 load_model_wo_clip(model, synth.synth_unet_state_dict()); model.to("cuda"); model.eval()
-x = torch.randn(8, 1, 32, device="cuda"); t = torch.full((8,), 500, device="cuda")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+WIDE = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # wide form with this design batch (0: latency form)
+model.set_wide(WIDE)
+x = torch.randn(B, 1, 32, device="cuda"); t = torch.full((B,), 500, device="cuda")
 for _ in range(3):
     model(x, t, y={})
 torch.cuda.synchronize()
