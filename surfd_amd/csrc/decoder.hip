@@ -185,6 +185,12 @@ typedef f16x8 __attribute__((address_space(1))) gf16x8;
 #ifndef SURFD_DEC_MIX
 #define SURFD_DEC_MIX 1
 #endif
+#ifndef SURFD_DEC_GRAD_W
+#define SURFD_DEC_GRAD_W 2        // value pairs of the gradient kernel's epilogues processed stage by stage (2 / 4 / 8: 35 / 37 / 46 spilled registers, 413 TFLOP/s each)
+#endif
+#ifndef SURFD_DEC_GRAD_MIX
+#define SURFD_DEC_GRAD_MIX 0      // the same two mixed FMAs in the gradient kernel's epilogues: 8 % fewer epilogue instructions, 46 instead of 37 spilled registers, 411.7 against 413.4 TFLOP/s
+#endif
 __device__ __forceinline__ unsigned split_low_pair(unsigned h, float u0, float u1) {
 #if SURFD_DEC_MIX
     unsigned l;
@@ -460,8 +466,13 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: keeps weight bases in SGPRs
     // per-lane LDS bases of this wave's accumulator footprint in X (one per point tile): every
     // element (mt, nt, r) is then base + compile-time offset (< 64 KB, fits the ds immediate)
-    float *const xb0 = X + (4 * (lane >> 5)) * XS + 128 * wave + col;
-    float *const xb1 = xb0 + 32 * XS;
+    typedef float __attribute__((address_space(3))) lds_f32;       // LDS-typed: stays a ds_write through the asm below
+    lds_f32 *xb0 = (lds_f32 *)(X + (4 * (lane >> 5)) * XS + 128 * wave + col);
+    lds_f32 *xb1 = xb0 + 32 * XS;
+    // In front of a block of XAT stores in the f16x2 gradient kernel: makes the two bases opaque at that point, so the ~64
+    // (base + constant) addresses the stores need are formed there, next to their use, instead of in the kernel prologue —
+    // from where the register allocator carried them through every GEMM in scratch (88 of the kernel's spilled registers)
+    auto fresh_xat_bases = [&]() { if constexpr (GRAD && F16X2) asm volatile("" : "+v"(xb0), "+v"(xb1)); };
 #define XAT(mt, nt, r) ((mt) ? xb1 : xb0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 32 * (nt)]
     // f16x2 mode: word (wave, q, col) of plane `pl` in the same rows (see the layout comment at the top)
     typedef unsigned __attribute__((address_space(3))) lds_u32;
@@ -494,38 +505,43 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                     continue;
                 }
                 // gradient kernel (more live state: gates, both accumulators): one accumulator-tile pair at a time bounds
-                // the live ranges, and four independent value pairs are processed stage by stage (measured +6 %)
+                // the live ranges, and SURFD_DEC_GRAD_W independent value pairs are processed stage by stage (measured +6 %)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r0 = 0; r0 < 16; r0 += 4) {
-                    float t0[4], t1[4];
-                    f32x2 u[4], rr[4];
-                    f16x2 h[4], l[4];
+                for (int r0 = 0; r0 < 16; r0 += SURFD_DEC_GRAD_W) {
+                    float t0[SURFD_DEC_GRAD_W], t1[SURFD_DEC_GRAD_W];
+                    f32x2 u[SURFD_DEC_GRAD_W];
+                    f16x2 h[SURFD_DEC_GRAD_W];
+                    unsigned l[SURFD_DEC_GRAD_W];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < SURFD_DEC_GRAD_W; ++i) {
                         t0[i] = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r0 + i], sb[2 * q]);
                         t1[i] = __builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r0 + i], sb[2 * q + 1]);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < SURFD_DEC_GRAD_W; ++i) {
                         umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0[i], t1[i]));      // one v_max3_f32: range accounting
                         if constexpr (GRAD) {                                             // ReLU gates for the reverse sweep
-                            if (t0[i] > 0.f) mk[mword(mt, 2 * q)] |= 1u << mbit(mt, 2 * q, r0 + i);
-                            if (t1[i] > 0.f) mk[mword(mt, 2 * q + 1)] |= 1u << mbit(mt, 2 * q + 1, r0 + i);
+                            mk[mword(mt, 2 * q)] |= t0[i] > 0.f ? 1u << mbit(mt, 2 * q, r0 + i) : 0u;              // branch-free: compare, select, or
+                            mk[mword(mt, 2 * q + 1)] |= t1[i] > 0.f ? 1u << mbit(mt, 2 * q + 1, r0 + i) : 0u;
                         }
                         u[i].x = __builtin_amdgcn_fmed3f(t0[i], 0.f, 65504.f);
                         u[i].y = __builtin_amdgcn_fmed3f(t1[i], 0.f, 65504.f);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) h[i] = __builtin_convertvector(u[i], f16x2);      // one v_cvt_pk_f16_f32
+                    for (int i = 0; i < SURFD_DEC_GRAD_W; ++i) h[i] = __builtin_convertvector(u[i], f16x2);      // one v_cvt_pk_f16_f32
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rr[i] = u[i] - __builtin_convertvector(h[i], f32x2);
+                    for (int i = 0; i < SURFD_DEC_GRAD_W; ++i) {
+#if SURFD_DEC_GRAD_MIX
+                        l[i] = split_low_pair(__builtin_bit_cast(unsigned, h[i]), u[i].x, u[i].y);      // same bits as convert back, subtract, convert
+#else
+                        l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(u[i] - __builtin_convertvector(h[i], f32x2), f16x2));
+#endif
+                    }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) l[i] = __builtin_convertvector(rr[i], f16x2);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < SURFD_DEC_GRAD_W; ++i) {
                         XW(mt, q, r0 + i, 0) = __builtin_bit_cast(unsigned, h[i]);
-                        XW(mt, q, r0 + i, 1) = __builtin_bit_cast(unsigned, l[i]);
+                        XW(mt, q, r0 + i, 1) = l[i];
                     }
                 }
             }
@@ -568,6 +584,12 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
         // 64-bit layer addresses out of the tile loop and spilling them to scratch
         const float *wpack_ = P.wpack, *vecs_ = P.vecs, *tab_ = tab_sample;
         const _Float16 *whf = P.whf;
+        // f16x2 gradient kernel: the thread index is made opaque per tile and the names below shadow the kernel-level ones, so
+        // the dozen LDS addresses of the fetch / encode / output phases are formed where they are used instead of in the
+        // prologue (from where they were carried through every GEMM in scratch).  No asm, no change for the other kernels.
+        int tid_tile = threadIdx.x;
+        if constexpr (GRAD && F16X2) asm volatile("" : "+v"(tid_tile));
+        const int tid = tid_tile, lane = tid & 63, wave = tid >> 6, col = lane & 31;
         int cb = 128 * wave + col;          // first of this lane's four channels (+32 per tile)
         asm volatile("" : "+s"(wpack_), "+s"(vecs_), "+s"(tab_));
         if constexpr (F16X2) asm volatile("" : "+s"(whf), "+v"(cb), "+v"(xw0), "+v"(xw1));
@@ -856,7 +878,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                 sb[nt] = nsb[nt];
                 wo[nt] = vecs[VOFF_WOUT + c];
             }
-            if constexpr (GRAD) { msk[2 * NB][0] = msk[2 * NB][1] = msk[2 * NB][2] = msk[2 * NB][3] = 0u; }
+            fresh_xat_bases();
+            unsigned mlast[4] = {0u, 0u, 0u, 0u};      // gates of the last layer, built in registers and stored once
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -864,9 +887,10 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float u = a10[nt] * net[mt][nt][r] + sb[nt];
-                        if constexpr (GRAD) if (u > 0.f) msk[2 * NB][mword(mt, nt)] |= 1u << mbit(mt, nt, r);
+                        if constexpr (GRAD) mlast[mword(mt, nt)] |= u > 0.f ? 1u << mbit(mt, nt, r) : 0u;
                         XAT(mt, nt, r) = fmaxf(u, 0.f) * wo[nt];
                     }
+            if constexpr (GRAD) { msk[2 * NB][0] = mlast[0]; msk[2 * NB][1] = mlast[1]; msk[2 * NB][2] = mlast[2]; msk[2 * NB][3] = mlast[3]; }
         }
         TPHASE(2);
         TBAR();
@@ -1056,6 +1080,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
             }
             }
             // X <- g ; e2 = fc_p^T g  (64 x 64)
+            fresh_xat_bases();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

@@ -42,7 +42,10 @@ def test_eight_wave_forward_kernel_fits_two_waves_per_simd(meta):
 
 def test_gradient_decoder_kernel_spill_bound(meta):
     k = _one(meta, "void surfd::decoder_kernel<true, true>")
-    assert k[".vgpr_spill_count"] <= 128          # round 2: 371; all of it in the epilogues, none inside a GEMM loop
+    # round 2: 371, mid round 3: 101.  What is left: 16 accumulator registers parked across the first epilogue of a tile and
+    # a dozen per-tile scalars; the 44 words of ReLU gates live in scratch by design (indexed by the layer loop) and are not spills
+    assert k[".vgpr_spill_count"] <= 40
+    assert k[".private_segment_fixed_size"] <= 384
 
 
 def test_conv_kernels_keep_two_workgroups_per_cu(meta):
