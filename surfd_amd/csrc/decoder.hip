@@ -433,6 +433,61 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][4]) {
 __device__ __forceinline__ constexpr int mword(int mt, int nt) { return (mt * 4 + nt) >> 1; }
 __device__ __forceinline__ constexpr int mbit(int mt, int nt, int r) { return ((mt * 4 + nt) & 1) * 16 + r; }
 
+// Positional encoding of a 64-point tile (reference AutoEncoder/models/coordsenc.py: x, then per frequency 2^f, f = 0..9,
+// [sin(2^f x), sin(2^f y), sin(2^f z), cos(2^f x), cos(2^f y), cos(2^f z)]; column 63 is the pad) straight into the split
+// fp16 planes of X's rows (identity k-slot order: feature j = half j of the high plane, the low plane 512 halves behind).
+// TPP threads per point; thread `part` takes the (coordinate, frequency) pairs part, part + TPP, ... of the 30: ONE range
+// reduction per angle gives both its features (the old form evaluated a generic feature(j) — index arithmetic, both sinf
+// and cosf — per column: 3.4 % of a tile's cycles, profiles/r03_decoder_variants.md).  Pre-encoded inputs (PT_EMB) are copied.
+template <int TPP>
+__device__ __forceinline__ void encode_tile_f16x2(const PtIO &io, long e0, long npts, const float *PT, float *X, int tid, int &sat_flag) {
+    constexpr int LOG2 = TPP == 8 ? 3 : 2;
+    static_assert(TPP == 4 || TPP == 8, "threads per point");
+    const int p = tid >> LOG2, part = tid & (TPP - 1);
+    _Float16 *hrow = reinterpret_cast<_Float16 *>(reinterpret_cast<unsigned *>(X) + p * XS);
+    auto put = [&](int j, float u) {
+        const _Float16 h = (_Float16)u;
+        hrow[j] = h;
+        hrow[512 + j] = (_Float16)(u - (float)h);
+    };
+    if (io.mode == PT_EMB) {
+        const long e = e0 + p;
+        bool bad = false;
+#pragma unroll 2
+        for (int i = 0; i < 64 / TPP; ++i) {
+            const int j = part * (64 / TPP) + i;
+            float u = (e < npts && j < io.emb_dim) ? io.xyz[e * io.emb_dim + j] : 0.f;
+            bad |= __builtin_fabsf(u) > 65504.f;
+            u = __builtin_amdgcn_fmed3f(u, -65504.f, 65504.f);
+            put(j, u);
+        }
+        sat_flag |= __any(bad);
+        return;
+    }
+    const float x = PT[p * 4 + 0], y = PT[p * 4 + 1], z = PT[p * 4 + 2];
+    {
+        float u = part == 0 ? x : (part == 1 ? y : z);
+        const bool bad = part < 3 && __builtin_fabsf(u) > 65504.f;
+        sat_flag |= __any(bad);
+        u = __builtin_amdgcn_fmed3f(u, -65504.f, 65504.f);
+        if (part < 3) put(part, u);
+        if (part == 3) put(63, 0.f);
+    }
+    int f = part / 3, r = part - 3 * (part / 3);
+#pragma unroll
+    for (int q0 = 0; q0 < 30; q0 += TPP) {
+        if (q0 + part < 30) {
+            const float a = (r == 0 ? x : (r == 1 ? y : z)) * (float)(1 << f);      // exact: power-of-two scale
+            float sn, cs;
+            sincosf(a, &sn, &cs);
+            put(3 + 6 * f + r, sn);
+            put(6 + 6 * f + r, cs);
+        }
+        r += TPP % 3; f += TPP / 3;
+        if (r >= 3) { r -= 3; ++f; }
+    }
+}
+
 // Optional phase timing of the forward kernel (-DSURFD_DEC_STAMPS, debugging only): shader-clock cycles of
 // workgroup 0 / wave 0 accumulated per phase: 0 fetch+encode, 1 GEMM loops, 2 epilogues, 3 barrier waits, 4 output
 #ifdef SURFD_DEC_STAMPS
@@ -645,30 +700,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                 }
             }
         } else {
-            // split planes in X's row layout (identity k-slot order for the first layer)
-            const int p = tid >> 2, part = tid & 3;
-            const long e = e0 + p;
-            const float c3[3] = {PT[p * 4 + 0], PT[p * 4 + 1], PT[p * 4 + 2]};
-            auto feature = [&](int j) -> float {
-                if (io.mode == PT_EMB) return (e < npts && j < io.emb_dim) ? io.xyz[e * io.emb_dim + j] : 0.f;
-                if (j < 3) return c3[j];
-                if (j == 63) return 0.f;
-                const int f = (j - 3) / 6, r = (j - 3) % 6;
-                const float a = c3[r % 3] * (float)(1 << f);      // exact: power-of-two scale
-                return (r < 3) ? sinf(a) : cosf(a);
-            };
-            unsigned *row = reinterpret_cast<unsigned *>(X) + p * XS + part * 8;
-#pragma unroll 2
-            for (int i = 0; i < 8; ++i) {
-                f32x2 u = {feature(part * 16 + 2 * i), feature(part * 16 + 2 * i + 1)};
-                sat_flag |= __any(__builtin_fmaxf(__builtin_fabsf(u.x), __builtin_fabsf(u.y)) > 65504.f);
-                u.x = __builtin_amdgcn_fmed3f(u.x, -65504.f, 65504.f);
-                u.y = __builtin_amdgcn_fmed3f(u.y, -65504.f, 65504.f);
-                unsigned hi, lo;
-                split2(u, hi, lo);
-                row[i] = hi;
-                row[256 + i] = lo;
-            }
+            encode_tile_f16x2<4>(io, e0, npts, PT, X, tid, sat_flag);
         }
         if constexpr (F16X2) gemm_request_f16x2<KS_E>(ws, whf + (size_t)(4 * wave_u) * KS_E * 2 * 512, lane);
         TPHASE(0);
@@ -1304,6 +1336,10 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
         const gfloat *vecs = (const gfloat *)vecs_, *tab = (const gfloat *)tab_;
         const size_t woff_e = (size_t)(2 * wave_u) * KS_E * 2 * 512, woff = (size_t)(2 * wave_u) * KS_H * 2 * 512;
         __syncthreads();        // previous tile's readers of PT / LOG are done
+        {   // fetch + encode with the thread index opaque: their LDS addresses are formed here, not carried from the prologue in scratch
+        int tid_fe = threadIdx.x;
+        asm volatile("" : "+v"(tid_fe));
+        const int tid = tid_fe;
         // ---- 1. fetch points ------------------------------------------------------------------
         if (tid < TP) {
             const long e = e0 + tid;
@@ -1319,30 +1355,7 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
         }
         __syncthreads();
         // ---- 2. positional encoding, split planes in X's row layout (identity k-slot order): 8 threads per point ------
-        {
-            const int p = tid >> 3, part = tid & 7;
-            const long e = e0 + p;
-            const float c3[3] = {PT[p * 4 + 0], PT[p * 4 + 1], PT[p * 4 + 2]};
-            auto feature = [&](int j) -> float {
-                if (io.mode == PT_EMB) return (e < npts && j < io.emb_dim) ? io.xyz[e * io.emb_dim + j] : 0.f;
-                if (j < 3) return c3[j];
-                if (j == 63) return 0.f;
-                const int f = (j - 3) / 6, r = (j - 3) % 6;
-                const float a = c3[r % 3] * (float)(1 << f);      // exact: power-of-two scale
-                return (r < 3) ? sinf(a) : cosf(a);
-            };
-            unsigned *row = reinterpret_cast<unsigned *>(X) + p * XS + part * 4;
-#pragma unroll 2
-            for (int i = 0; i < 4; ++i) {
-                f32x2 u = {feature(part * 8 + 2 * i), feature(part * 8 + 2 * i + 1)};
-                sat_flag |= __any(__builtin_fmaxf(__builtin_fabsf(u.x), __builtin_fabsf(u.y)) > 65504.f);
-                u.x = __builtin_amdgcn_fmed3f(u.x, -65504.f, 65504.f);
-                u.y = __builtin_amdgcn_fmed3f(u.y, -65504.f, 65504.f);
-                unsigned hi, lo;
-                split2(u, hi, lo);
-                row[i] = hi;
-                row[256 + i] = lo;
-            }
+        encode_tile_f16x2<8>(io, e0, npts, PT, X, tid, sat_flag);
         }
         gemm8_request<KS_E>(ws, whf + woff_e, lane);
         __syncthreads();

@@ -306,6 +306,7 @@ static PtIO base_io(const surfd_grid *g) {
     PtIO io;
     memset(&io, 0, sizeof(io));
     io.N = g->N; io.voxel = g->voxel; io.origin = g->origin; io.s = 1;
+    if (g->N > 0 && (g->N & (g->N - 1)) == 0) { int l = 0; while ((1 << l) < g->N) ++l; io.log2N1 = l + 1; }
     return io;
 }
 

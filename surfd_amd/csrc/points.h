@@ -27,6 +27,7 @@ struct PtIO {
     const int *count_dev;    // device-side element count of `list` (nullable)
     long n;                  // host-side point count when count_dev == nullptr
     int N, s;                // grid resolution, lattice stride
+    int log2N1;              // log2(N) + 1 when N is a power of two (index arithmetic by shifts), 0 otherwise / unknown
     float voxel, origin;
     int emb_dim;
     // sinks (all nullable)
@@ -44,31 +45,41 @@ __device__ __forceinline__ long pt_count(const PtIO &io) {
     return io.mode == PT_CHILDREN ? 7 * c : (io.mode == PT_CHILDREN8 ? 8 * c : c);
 }
 
-// voxel index of point e (grid modes only)
+// voxel index of point e (grid modes only).  Point numbers fit 32 bits (at most 8 children of at most N^3 / 8 cells, N <= 1024):
+// the divisions by 7 / by the lattice width are 32-bit (the 64-bit forms were ~100 instructions each on the one wave that fetches a
+// tile's points while the other seven wait)
 __device__ __forceinline__ int pt_voxel(const PtIO &io, long e) {
+    const unsigned ee = (unsigned)e;
     switch (io.mode) {
         case PT_LIST: return io.list[e];
         case PT_CHILDREN: {
-            const int parent = io.list[e / 7];
-            const int c = (int)(e % 7) + 1;
+            const unsigned pe = ee / 7u;
+            const int parent = io.list[pe];
+            const int c = (int)(ee - 7u * pe) + 1;
             return parent + (((c >> 2) & 1) * io.N * io.N + ((c >> 1) & 1) * io.N + (c & 1)) * io.s;
         }
         case PT_CHILDREN8: {
-            const int parent = io.list[e >> 3];
-            const int c = (int)(e & 7);
+            const int parent = io.list[ee >> 3];
+            const int c = (int)(ee & 7u);
             return parent + (((c >> 2) & 1) * io.N * io.N + ((c >> 1) & 1) * io.N + (c & 1)) * io.s;
         }
         case PT_LATTICE: {
-            const int n = io.N / io.s;
-            const int K = (int)(e % n), J = (int)((e / n) % n), I = (int)(e / ((long)n * n));
-            return (I * io.N * io.N + J * io.N + K) * io.s;
+            const unsigned n = (unsigned)(io.N / io.s);
+            const unsigned q = ee / n, K = ee - q * n, I = q / n, J = q - I * n;
+            return (int)((I * io.N * io.N + J * io.N + K) * io.s);
         }
         default: return (int)e;   // PT_DENSE
     }
 }
 
 __device__ __forceinline__ void voxel_xyz(const PtIO &io, int idx, float &x, float &y, float &z) {
-    const int k = idx % io.N, j = (idx / io.N) % io.N, i = idx / (io.N * io.N);
+    int i, j, k;
+    if (io.log2N1) {          // uniform: every grid the drivers use is a power of two
+        const int l = io.log2N1 - 1;
+        k = idx & (io.N - 1); j = (idx >> l) & (io.N - 1); i = idx >> (2 * l);
+    } else {
+        k = idx % io.N; j = (idx / io.N) % io.N; i = idx / (io.N * io.N);
+    }
     x = __fadd_rn(__fmul_rn((float)i, io.voxel), io.origin);
     y = __fadd_rn(__fmul_rn((float)j, io.voxel), io.origin);
     z = __fadd_rn(__fmul_rn((float)k, io.voxel), io.origin);

@@ -37,7 +37,7 @@ def test_eight_wave_forward_kernel_fits_two_waves_per_simd(meta):
     the ISA when the kernel was written; here: the bound)."""
     k = _one(meta, "surfd::decoder_fwd8_kernel")
     assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256
-    assert k[".vgpr_spill_count"] <= 32 and k[".private_segment_fixed_size"] <= 128
+    assert k[".vgpr_spill_count"] <= 16 and k[".private_segment_fixed_size"] <= 64          # 13 / 56 B since the fetch / encode phases form their addresses in place
 
 
 def test_gradient_decoder_kernel_spill_bound(meta):
