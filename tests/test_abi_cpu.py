@@ -37,6 +37,15 @@ def test_header_symbols_exported(lib):
     assert set(N.EXPORTED_SYMBOLS) == set(declared), set(N.EXPORTED_SYMBOLS) ^ set(declared)
 
 
+def test_integration_appendix_lists_every_export():
+    """INTEGRATION.md's appendix (tools/abi_table.py) names, for every export, the reference interface it stands for and the
+    module that binds it; an export added to the header without regenerating the appendix fails here."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    appendix = doc[doc.index("## Appendix: every export"):]
+    missing = [s for s in _declared_symbols() if f"| `{s}` |" not in appendix]
+    assert not missing, missing
+
+
 def test_version_and_no_device(lib):
     assert lib.surfd_abi_version() == 1
     assert lib.surfd_device_count() >= 0
