@@ -13,7 +13,7 @@ def exports():
     text = open(os.path.join(ROOT, "include", "surfd_hip.h")).read()
     out, section, comment, in_banner, banner = [], [], [], False, []
     pos = 0
-    tok = re.compile(r"/\*(.*?)\*/|\b(?:int|void|const char \*|long long)\s*\*?\s*(surfd_[a-z0-9_]+)\s*\(|;", re.S)
+    tok = re.compile(r"/\*(.*?)\*/|\b(?:int64_t|int|void|const char \*|long long)\s*\*?\s*(surfd_[a-z0-9_]+)\s*\(|;", re.S)
     for m in tok.finditer(text):
         if m.group(1) is not None:
             c = m.group(1)
