@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                     for (int r = 0; r < 16; ++r) {
                         const float t0 = __builtin_fmaf(sa[2 * q], v[mt][2 * q][r], sb[2 * q]);
                         const float t1 = __builtin_fmaf(sa[2 * q + 1], v[mt][2 * q + 1][r], sb[2 * q + 1]);
-                        umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));          // one v_max3_f32: range accounting
+                        umax = __builtin_fmaxf(__builtin_fmaxf(umax, t0), t1);          // one v_max3_f32 per pair (the other nesting costs 1.5): range accounting
                         const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
                         const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
                         const f32x2 u = {u0, u1};
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
                     }
 #pragma unroll
                     for (int i = 0; i < SURFD_DEC_GRAD_W; ++i) {
-                        umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0[i], t1[i]));      // one v_max3_f32: range accounting
+                        umax = __builtin_fmaxf(__builtin_fmaxf(umax, t0[i]), t1[i]);      // one v_max3_f32: range accounting
                         if constexpr (GRAD) {                                             // ReLU gates for the reverse sweep
                             mk[mword(mt, 2 * q)] |= t0[i] > 0.f ? 1u << mbit(mt, 2 * q, r0 + i) : 0u;              // branch-free: compare, select, or
                             mk[mword(mt, 2 * q + 1)] |= t1[i] > 0.f ? 1u << mbit(mt, 2 * q + 1, r0 + i) : 0u;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
             const int mt = (base + i) >> 4, r = (base + i) & 15;
             const float t0 = __builtin_fmaf(sa[2], v[mt][2][r], sb[2]);
             const float t1 = __builtin_fmaf(sa[3], v[mt][3][r], sb[3]);
-            umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));
+            umax = __builtin_fmaxf(__builtin_fmaxf(umax, t0), t1);
             const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
             const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
             const f32x2 u = {u0, u1};
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
             for (int r = 0; r < 16; ++r) {
                 const float t0 = __builtin_fmaf(sa[0], v[mt][0][r], sb[0]);
                 const float t1 = __builtin_fmaf(sa[1], v[mt][1][r], sb[1]);
-                umax = __builtin_fmaxf(umax, __builtin_fmaxf(t0, t1));
+                umax = __builtin_fmaxf(__builtin_fmaxf(umax, t0), t1);
                 const float u0 = __builtin_amdgcn_fmed3f(t0, 0.f, 65504.f);
                 const float u1 = __builtin_amdgcn_fmed3f(t1, 0.f, 65504.f);
                 const f32x2 u = {u0, u1};
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
             }
             gemm8_request<KS_H>(ws, W0, lane);
             __syncthreads();
-            zero8(tmp);
+            zero8(tmp);       // (clearing it inside the preceding GEMM instead does not survive the optimiser: both values reaching the loop head are the constant)
             float sa1[2], sbb[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
