@@ -108,6 +108,10 @@ def parse():
     ap.add_argument("--no-trace", action="store_true", help="skip the untimed W-trace measurement")
     ap.add_argument("--no-e2", action="store_true", help="skip the untimed E2 stage figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict-C3 pass (one batch-8 request in flight, sequential)")
+    ap.add_argument("--strict-steps", type=int, default=3, help="requests timed by the strict-C3 pass")
+    ap.add_argument("--no-trace-e2", action="store_true", help="skip the timed W-trace / E2 pass (trained-model-like field through marching cubes)")
+    ap.add_argument("--trace-steps", type=int, default=0, help="steps timed by the W-trace / E2 pass (0 = --steps)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     if a.resolution is None:
@@ -316,16 +320,30 @@ def time_trace(dec, lat, lists, reps=2):
 
 
 def committed_traffic():
-    """HBM traffic of the dominant kernel from the committed PMC pass of this command (profiles/, collected in its
-    own rocprofv3 --pmc run as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per the gfx950 note)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    """(profile, note): HBM traffic of the dominant kernels from the committed PMC passes of this command (profiles/,
+    collected in their own rocprofv3 --pmc runs as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per the gfx950 note).
+    A profile names the kernel sources it was collected with (sha256); if they have changed since, nothing is quoted."""
+    import hashlib
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
+        if not os.path.exists(path):
+            continue
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        want = prof.get("source_sha256")
+        if not want:
+            return None, f"profiles/{name} does not name the kernel sources it was collected with: not quoted"
+        for rel, digest in want.items():
             try:
-                return json.load(open(path))
-            except (OSError, ValueError):
-                continue
-    return None
+                have = hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+            except OSError:
+                have = None
+            if have != digest:
+                return None, f"profiles/{name} was collected with a different {rel}: stale, not quoted"
+        return prof, f"committed profile profiles/{name} (not a counter of this run; kernel sources unchanged since): " + str(prof.get("source"))
+    return None, "no committed PMC profile"
 
 
 def build_models(cfg, latent, precision, unet_precision="f16x2"):
@@ -353,18 +371,187 @@ def build_models(cfg, latent, precision, unet_precision="f16x2"):
     return model, diffusion, dec
 
 
+class Job:
+    """One schedule over one workload: everything `run_steps` needs, built once.  The headline job, the strict-C3 job (one
+    batch-8 request in flight, sequential) and the timed W-trace / E2 job share the models, the noise and the decoder."""
+
+    def __init__(self, a, world, rank, cfg, model, chains_pool, diffusion, dec, noise_bank, ctx_bank, *, workload, endpoint,
+                 schedule, loop_batches, n_chains, wide, trace=None, trace_grid=None):
+        from surfd_amd.cbndec import make_udf_func
+        from surfd_amd.meshudf import GridFiller
+        from surfd_amd.meshudf import fill_grids as fill_grids_batch
+        from surfd_amd.parallel import BatchPipeline, PhasedPipeline
+        self.a, self.world, self.rank, self.cfg = a, world, rank, cfg
+        self.diffusion, self.dec = diffusion, dec
+        self.workload, self.endpoint, self.schedule = workload, endpoint, schedule
+        T, B, N = diffusion.num_timesteps, a.batch, a.resolution
+        self.T, self.B, self.N = T, B, N
+        conditioned = cfg["cond_mode"] != "no_cond"
+        self.n_chains = n_chains = max(1, n_chains) if schedule != "sequential" else 1
+        self.loop_batches = loop_batches
+        self.chains = chains = chains_pool[:n_chains]
+        for m in chains:
+            m.set_wide(wide if schedule == "phased" else 0)
+            m.set_cu_budget(a.loop_cus if schedule == "overlap" else 256)
+        if cfg["cfg"]:
+            from surfd_amd.mdm import ClassifierFreeSampleModel
+            wrapped = [ClassifierFreeSampleModel(m) for m in chains]
+        else:
+            wrapped = chains
+
+        def loop_kwargs(first, n):
+            if not conditioned:
+                return {"y": {}}
+            y = {"context": ctx_bank[first:first + n].reshape(n * B, -1).contiguous()}
+            if cfg["cfg"]:
+                y["scale"] = torch.full((n * B,), 3.0, device="cuda")
+            return {"y": y}
+
+        def sample_latents(first, n, chain=0):
+            """ONE reverse loop over the latents of steps [first, first + n) -> [n * B, 1, L]"""
+            noise = noise_bank[first:first + n].permute(1, 0, 2, 3, 4).reshape(T + 1, n * B, 1, a.latent).contiguous()
+            return diffusion.p_sample_loop(wrapped[chain], (n * B, 1, a.latent), clip_denoised=False, model_kwargs=loop_kwargs(first, n),
+                                           noise_stream=noise, fused=True)
+        self.sample_latents = sample_latents
+
+        self.trace = trace if workload == "trace" else None
+        trace = self.trace
+        self.filler = filler = GridFiller(N)
+        self.fillers = fillers = ([filler] + [GridFiller(N) for _ in range(B - 1)] if a.batch_grids and B <= 8 else [filler]) if trace is None else [filler]
+        self.udf = udf = [torch.empty(N, N, N, device="cuda") for _ in range(B)] if trace is None else None
+        self.grads = grads = [torch.empty(N, N, N, 3, device="cuda") for _ in range(B)] if trace is None else None
+        self.mesher = None
+        if endpoint == "e2":
+            from surfd_amd.mcubes import BandMesher
+            threads = a.mesh_threads or max(1, min(8, (os.cpu_count() or 8) // world - n_chains))
+            self.mesher = BandMesher(N, threads=threads, slots=2 * B)
+        mesher = self.mesher
+
+        def fill_grids(step, lat):
+            dec.bind_latents(lat.reshape(B, a.latent))
+            if trace is not None:                            # W-trace: the decoder kernels over the trained-model-like query lists
+                for k in range(B):
+                    for kind, c in trace:
+                        (dec.udf if kind == "fwd" else dec.udf_and_ngrad)(c, k)
+                    if mesher is not None:                   # ... and the mesh of the same field (222 793 vertices): band compaction, D2H, host mesher
+                        mesher.submit(trace_grid[0], trace_grid[1], tag=(step, k))
+                return
+            if len(fillers) == B:
+                # all shapes of the step level by level together: one persistent decoder launch per level (meshudf.fill_grids)
+                fill_grids_batch(fillers, dec, list(range(B)), [(udf[k], grads[k]) for k in range(B)])
+            else:
+                for k in range(B):
+                    filler.fill_grid(make_udf_func(dec, lat[k], sample=k), 2 ** 16, out=(udf[k], grads[k]), stats=False)
+            if mesher is not None:
+                for k in range(B):
+                    mesher.submit(udf[k], grads[k], tag=(step, k))     # device-side band compaction + async D2H; meshing on host threads
+        self.fill_grids = fill_grids
+
+        if schedule == "phased":
+            self.pipe = PhasedPipeline(sample_latents, fill_grids, chains=n_chains, max_loop_batches=loop_batches, overlap_blocks=a.overlap_blocks,
+                                       decoder=dec, first_round_batches=a.first_round if a.overlap_blocks else 0)
+        elif schedule == "overlap":
+            self.pipe = BatchPipeline(dec, lambda s, q: sample_latents(s, 1, q), fill_grids, a.decoder_blocks, loop_chains=n_chains)
+        else:
+            self.pipe = None
+
+    def run_steps(self, k_steps):
+        """k_steps full passes (every step: reverse loop + B grids [+ B meshes]), start to finish."""
+        if k_steps <= 0:
+            return
+        if self.pipe is None:
+            for s in range(k_steps):
+                self.fill_grids(s, self.sample_latents(s, 1))
+        else:
+            self.pipe.run(k_steps)
+        if self.mesher is not None:
+            self.mesher.drain()                               # every mesh of the job is finished
+
+    def reset_totals(self):
+        if self.trace is None:
+            for f in self.fillers:
+                if f._handle is not None:
+                    f.totals(reset=True)
+        if self.mesher is not None:
+            self.mesher.reset_stats()
+
+    def measure(self, steps, warmup):
+        """warmup untimed steps, then exactly `steps` timed ones between barrier + synchronize on both sides."""
+        from surfd_amd import _native as Nn
+        L = Nn.lib()
+        B = self.B
+        self.run_steps(warmup)
+        if self.pipe is not None:
+            self.pipe.record_timeline = True                  # a few HIP events per round: time_share / per_rank come from them
+        torch.cuda.synchronize()
+        self.reset_totals()
+        barrier(self.world)
+        L.surfd_profile_enable(1)
+        t0 = time.perf_counter()
+        self.run_steps(steps)
+        torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t0
+        barrier(self.world)
+        elapsed = time.perf_counter() - t0
+        timeline = list(self.pipe.timeline) if self.pipe is not None and self.pipe.record_timeline else []
+        if self.pipe is not None:
+            self.pipe.record_timeline = False
+        L.surfd_profile_enable(0)
+        prof = {}
+        for kind, name in [(0, "dec_fwd"), (1, "dec_grad"), (2, "loop")]:
+            n, ms = C.c_int64(), C.c_double()
+            Nn.check(L.surfd_profile_read(kind, C.byref(n), C.byref(ms)))
+            prof[name] = (n.value, ms.value)
+        # ---- exact query counts of the timed region (kept on the device by the fills themselves) ------------------
+        if self.trace is None:
+            tot = [f.totals(reset=True) for f in self.fillers]
+            fwd_total = float(sum(sum(t["fwd_per_level"]) for t in tot))
+            grad_total = float(sum(t["grad"] for t in tot))
+            assert sum(t["fills"] for t in tot) == B * steps, (sum(t["fills"] for t in tot), B * steps)
+        else:
+            fwd_total = float(sum(c.shape[0] for k, c in self.trace if k == "fwd")) * B * steps
+            grad_total = float(sum(c.shape[0] for k, c in self.trace if k == "grad")) * B * steps
+        mesh_stats = self.mesher.stats() if self.mesher is not None else None
+        # time the loops had the chip: phased = up to the last loop of each round; otherwise they overlap the grids
+        a = self.a
+        if self.schedule == "phased" and timeline and a.overlap_blocks:
+            loop_phase_ms = timeline[0]["loops_done_ms"]         # only the first round's loops have the chip to themselves
+        elif self.schedule == "phased" and timeline:
+            prev, loop_phase_ms = 0.0, 0.0
+            for m in timeline:
+                loop_phase_ms += m["loops_done_ms"] - prev
+                prev = m["grids_done_ms"]
+        else:
+            loop_phase_ms = None
+        return {"elapsed": elapsed, "local_elapsed": local_elapsed, "timeline": timeline, "prof": prof, "fwd_total": fwd_total,
+                "grad_total": grad_total, "mesh_stats": mesh_stats, "loop_phase_ms": loop_phase_ms, "steps": steps}
+
+    def close(self):
+        if self.mesher is not None:
+            self.mesher.close()
+            self.mesher = None
+        self.udf = self.grads = None
+
+
+def decoder_rooflines(m, f16):
+    """forward and forward+reverse decoder kernels of a measured pass against the matrix peak (algorithmic flops)."""
+    peak = F16_MFMA_PEAK_TF if f16 else FP32_MFMA_PEAK_TF
+    fl, fms = m["prof"]["dec_fwd"]
+    gl, gms = m["prof"]["dec_grad"]
+    fwd = m["fwd_total"] * FWD_FLOP / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
+    grd = m["grad_total"] * 2 * FWD_FLOP / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+    return {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+            "decoder_fwd": {"achieved": fwd, "frac": fwd / peak, "launches": fl, "avg_launch_ms": fms / max(fl, 1), "ms": fms},
+            "decoder_fwd_bwd": {"achieved": grd, "frac": grd / peak, "launches": gl, "avg_launch_ms": gms / max(gl, 1), "ms": gms,
+                                "accounting": "2 x forward flops per gradient query"}}
+
+
 def main():
     a = parse()
     world, rank, local = setup_dist(a.gpus)
     if a.mode == "grid-shard":
         return grid_shard_main(a, world, rank)
-    from surfd_amd import _native as Nn
     from surfd_amd import synth
-    from surfd_amd.cbndec import make_udf_func
-    from surfd_amd.meshudf import GridFiller
-    from surfd_amd.meshudf import fill_grids as fill_grids_batch
-    from surfd_amd.parallel import BatchPipeline, PhasedPipeline
-    L = Nn.lib()
     cfg = CONFIGS[a.config]
     model, diffusion, dec = build_models(cfg, a.latent, a.decoder_precision, a.unet_precision)
     if a.diffusion_steps != 1000:
@@ -378,24 +565,6 @@ def main():
     gidx = lambda s: (s * world + rank) * B
     noise_bank = torch.stack([synth.synth_noise_batch(T, gidx(s), B, a.latent) for s in range(n_steps_max)], 0).cuda()   # [S, T+1, B, 1, L]
     ctx_bank = torch.stack([synth.synth_context(gidx(s), B) for s in range(n_steps_max)], 0).cuda() if conditioned else None
-    sampler_model = model
-    if cfg["cfg"]:
-        from surfd_amd.mdm import ClassifierFreeSampleModel
-
-    def loop_kwargs(first, n):
-        if not conditioned:
-            return {"y": {}}
-        y = {"context": ctx_bank[first:first + n].reshape(n * B, -1).contiguous()}
-        if cfg["cfg"]:
-            y["scale"] = torch.full((n * B,), 3.0, device="cuda")
-        return {"y": y}
-
-    filler = GridFiller(N)
-    fillers = [filler] + [GridFiller(N) for _ in range(B - 1)] if a.batch_grids and B <= 8 else [filler]
-    udf = [torch.empty(N, N, N, device="cuda") for _ in range(B)]
-    grads = [torch.empty(N, N, N, 3, device="cuda") for _ in range(B)]
-    trace = make_trace(N) if a.workload == "trace" else None
-
     n_chains = max(1, a.loop_chains) if a.schedule != "sequential" else 1
     chains = [model] + [model.replica() for _ in range(n_chains - 1)]
     for m in chains[1:]:
@@ -403,115 +572,19 @@ def main():
     # (a conditioned loop keeps one embedding row per (iteration, latent) in HBM: 56 KB x T x latents = 4.5 GB for an
     # 80-wide loop — sized for 288 GB, not for a 16 GB card)
     loop_batches = a.loop_batches
-    if a.schedule == "phased":
-        for m in chains:
-            m.set_wide(a.wide_design_batch)
-    elif a.schedule == "overlap":
-        for m in chains:
-            m.set_cu_budget(a.loop_cus)
-    wrapped = [ClassifierFreeSampleModel(m) if cfg["cfg"] else m for m in chains]
-
-    def sample_latents(first, n, chain=0):
-        """ONE reverse loop over the latents of steps [first, first + n) -> [n * B, 1, L]"""
-        noise = noise_bank[first:first + n].permute(1, 0, 2, 3, 4).reshape(T + 1, n * B, 1, a.latent).contiguous()
-        return diffusion.p_sample_loop(wrapped[chain], (n * B, 1, a.latent), clip_denoised=False, model_kwargs=loop_kwargs(first, n),
-                                       noise_stream=noise, fused=True)
-
-    mesher = None
-    trace_grid = None
-    if a.endpoint == "e2" and trace is not None:
-        trace_grid = thin_shell_grid(N)                  # the field whose query lists the trace is: what a trained model's grids look like
-    if a.endpoint == "e2":
-        from surfd_amd.mcubes import BandMesher
-        threads = a.mesh_threads or max(1, min(8, (os.cpu_count() or 8) // world - n_chains))
-        mesher = BandMesher(N, threads=threads, slots=2 * B)
-
-    def fill_grids(step, lat):
-        dec.bind_latents(lat.reshape(B, a.latent))
-        if trace is not None:                            # W-trace: the decoder kernels over the trained-model-like query lists
-            for k in range(B):
-                for kind, c in trace:
-                    (dec.udf if kind == "fwd" else dec.udf_and_ngrad)(c, k)
-                if mesher is not None:                   # ... and the mesh of the same field (222 793 vertices): band compaction, D2H, host mesher
-                    mesher.submit(trace_grid[0], trace_grid[1], tag=(step, k))
-            return
-        if len(fillers) == B:
-            # all shapes of the step level by level together: one persistent decoder launch per level (meshudf.fill_grids)
-            fill_grids_batch(fillers, dec, list(range(B)), [(udf[k], grads[k]) for k in range(B)])
-        else:
-            for k in range(B):
-                filler.fill_grid(make_udf_func(dec, lat[k], sample=k), 2 ** 16, out=(udf[k], grads[k]), stats=False)
-        if mesher is not None:
-            for k in range(B):
-                mesher.submit(udf[k], grads[k], tag=(step, k))     # device-side band compaction + async D2H; meshing on host threads
-
-    if a.schedule == "phased":
-        pipe = PhasedPipeline(sample_latents, fill_grids, chains=n_chains, max_loop_batches=loop_batches, overlap_blocks=a.overlap_blocks,
-                              decoder=dec, first_round_batches=a.first_round if a.overlap_blocks else 0)
-    elif a.schedule == "overlap":
-        pipe = BatchPipeline(dec, lambda s, q: sample_latents(s, 1, q), fill_grids, a.decoder_blocks, loop_chains=n_chains)
-    else:
-        pipe = None
-
-    def run_steps(k_steps):
-        """k_steps full passes (every step: reverse loop + B grids [+ B meshes]), start to finish."""
-        if k_steps <= 0:
-            return
-        if pipe is None:
-            for s in range(k_steps):
-                fill_grids(s, sample_latents(s, 1))
-        else:
-            pipe.run(k_steps)
-        if mesher is not None:
-            mesher.drain()                                # every mesh of the job is finished
-
-    def reset_totals():
-        if trace is None:
-            for f in fillers:
-                if f._handle is not None:
-                    f.totals(reset=True)
-        if mesher is not None:
-            mesher.reset_stats()
-
-    run_steps(a.warmup)
-    if pipe is not None:
-        pipe.record_timeline = True                       # a few HIP events per round: time_share / per_rank come from them
-    torch.cuda.synchronize()
-    reset_totals()
-    barrier(world)
-    L.surfd_profile_enable(1)
-    t0 = time.perf_counter()
-    run_steps(a.steps)
-    torch.cuda.synchronize()
-    local_elapsed = time.perf_counter() - t0
-    barrier(world)
-    elapsed = time.perf_counter() - t0
-    timeline = list(pipe.timeline) if pipe is not None and pipe.record_timeline else []
+    trace = make_trace(N) if a.workload == "trace" else None
+    trace_grid = thin_shell_grid(N) if (a.endpoint == "e2" and trace is not None) else None   # the field whose query lists the trace is
+    job = Job(a, world, rank, cfg, model, chains, diffusion, dec, noise_bank, ctx_bank, workload=a.workload, endpoint=a.endpoint,
+              schedule=a.schedule, loop_batches=loop_batches, n_chains=n_chains, wide=a.wide_design_batch, trace=trace, trace_grid=trace_grid)
+    sample_latents = job.sample_latents
+    meas = job.measure(a.steps, a.warmup)
+    elapsed, local_elapsed, timeline, prof = meas["elapsed"], meas["local_elapsed"], meas["timeline"], meas["prof"]
+    fwd_total, grad_total, mesh_stats, loop_phase_ms = meas["fwd_total"], meas["grad_total"], meas["mesh_stats"], meas["loop_phase_ms"]
     if a.timeline:
         for m in timeline:
             print("[timeline] " + json.dumps(m), file=sys.stderr)
-    if pipe is not None:
-        pipe.record_timeline = False
-    L.surfd_profile_enable(0)
-    prof = {}
-    for kind, name in [(0, "dec_fwd"), (1, "dec_grad"), (2, "loop")]:
-        n, ms = C.c_int64(), C.c_double()
-        Nn.check(L.surfd_profile_read(kind, C.byref(n), C.byref(ms)))
-        prof[name] = (n.value, ms.value)
-    # ---- exact query counts of the timed region (kept on the device by the fills themselves) ----------------------
-    if trace is None:
-        tot = [f.totals(reset=True) for f in fillers]
-        fwd_total = float(sum(sum(t["fwd_per_level"]) for t in tot))
-        grad_total = float(sum(t["grad"] for t in tot))
-        assert sum(t["fills"] for t in tot) == B * a.steps, (sum(t["fills"] for t in tot), B * a.steps)
-    else:
-        fwd_total = float(sum(c.shape[0] for k, c in trace if k == "fwd")) * B * a.steps
-        grad_total = float(sum(c.shape[0] for k, c in trace if k == "grad")) * B * a.steps
     n_fwd, n_grad = fwd_total / (B * a.steps), grad_total / (B * a.steps)
-    mesh_stats = mesher.stats() if mesher is not None else None
-    if mesher is not None:
-        mesher.close()
-        mesher = None
+    job.close()
     # ---- untimed extras: one loop alone at the widest batch the schedule used --------------------------------------
     dec.set_grid_blocks(0)
     if a.schedule == "overlap" and a.loop_cus != 256:
@@ -547,9 +620,46 @@ def main():
         rccl_ranks = int(alllat.shape[0] // B)
     if rank != 0:
         return
+    f16 = a.decoder_precision == "f16x2"
+    # ---- the two other numbers of the line (N = 1 only, each its own timed region after the headline's) --------------
+    strict = None
+    if not a.no_strict and world == 1 and a.schedule == "phased" and a.workload == "real" and a.endpoint == "e1":
+        # BASELINE configs[2] read strictly: ONE batch-8 request in flight per GPU — its reverse loop (8 latents, the conv
+        # kernel's latency form), then its 8 grids, request after request on one stream
+        sj = Job(a, world, rank, cfg, model, chains, diffusion, dec, noise_bank, ctx_bank, workload="real", endpoint="e1",
+                 schedule="sequential", loop_batches=1, n_chains=1, wide=0)
+        k = max(1, min(a.strict_steps, n_steps_max))
+        sm = sj.measure(k, 1)
+        sj.close()
+        strict = {"value": B * k / sm["elapsed"], "unit": "shapes/s", "latency_s_per_request": sm["elapsed"] / k, "requests": k, "warmup": 1,
+                  "shapes_per_request": B, "requests_in_flight": 1,
+                  "reverse_loop_s_per_request": sm["prof"]["loop"][1] / max(sm["prof"]["loop"][0], 1) * 1e-3,
+                  "what": "one batch-8 request in flight per GPU (BASELINE configs[2] = batch 64 over 8 GPUs, read strictly): 1000-step loop over 8 "
+                          "latents (latency form of the conv kernel), then the request's 8 grids, sequentially on one stream"}
+    trace_e2 = None
+    if not a.no_trace_e2 and world == 1 and a.workload == "real" and a.endpoint == "e1" and a.schedule == "phased":
+        # the trained-model-like workload END TO END, timed: wide reverse loops + decoder over the thin-shell query lists + band
+        # compaction, pinned D2H and the host mesher, every mesh finished before the clock stops
+        torch.cuda.empty_cache()
+        tr = make_trace(N)
+        tg = thin_shell_grid(N)
+        tj = Job(a, world, rank, cfg, model, chains, diffusion, dec, noise_bank, ctx_bank, workload="trace", endpoint="e2",
+                 schedule="phased", loop_batches=loop_batches, n_chains=n_chains, wide=a.wide_design_batch, trace=tr, trace_grid=tg)
+        k = max(1, min(a.trace_steps or a.steps, n_steps_max))
+        tm = tj.measure(k, 1)
+        tstats = tm["mesh_stats"]
+        tj.close()
+        trace_e2 = {"status": "timed", "value": B * k / tm["elapsed"], "unit": "shapes/s", "steps": k, "warmup": 1, "ms_per_step": tm["elapsed"] / k * 1e3,
+                    "workload": f"W-trace ({N}^3 thin shell: {tm['fwd_total'] / (B * k):.0f} forward + {tm['grad_total'] / (B * k):.0f} gradient queries per shape), "
+                                "end point E2 (every mesh finished inside the timed region)",
+                    "roofline": decoder_rooflines(tm, f16),
+                    "time_share": ({"loops_alone_on_chip_ms": tm["loop_phase_ms"], "loops_frac": tm["loop_phase_ms"] / (tm["elapsed"] * 1e3)}
+                                   if tm["loop_phase_ms"] is not None else None),
+                    "mesher": tstats}
+        del tr, tg
+        torch.cuda.empty_cache()
     w_trace = None
     if not a.no_trace:
-        del udf, grads
         torch.cuda.empty_cache()
         w_trace = time_trace(dec, lat, trace if trace is not None else make_trace(N))
     shapes = world * B * a.steps
@@ -557,29 +667,18 @@ def main():
     grad_launches, grad_ms = prof["dec_grad"]
     loops, loop_ms = prof["loop"]
     algorithmic = fwd_total * FWD_FLOP / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
-    f16 = a.decoder_precision == "f16x2"
     peak = F16_MFMA_PEAK_TF if f16 else FP32_MFMA_PEAK_TF
-    kname = ("decoder_kernel<false, f16x2> (fused encode + 11-layer CBN MLP + sigmoid; split-fp16 operands, fp32 accumulate)"
+    kname = ("decoder_fwd8_kernel (fused encode + 11-layer CBN MLP + sigmoid; 8 waves per 64-point tile, split-fp16 operands, fp32 accumulate)"
              if f16 else "decoder_kernel<false> (fused encode + 11-layer CBN MLP + sigmoid)")
     dtype = ("f32 (every matrix product of decoder and denoiser as three split-fp16 products on the fp16 MFMA pipe with fp32 "
              "accumulation — fp32-class error, same golden tolerances as the exact-fp32 kernels; samplers, attention, "
              "embedding MLP and grid bookkeeping in exact fp32)") if f16 and a.unet_precision == "f16x2" else "f32"
-    pmc = committed_traffic()
+    pmc, pmc_note = committed_traffic()
     # reverse loop against its roofline: per evaluation max(weight bytes / HBM, latents * flops / matrix peak)
     lat_per_loop = alone_n * B
     flops_eval = lat_per_loop * UNET_FLOP_PER_SAMPLE.get(a.latent, 2.057e9 * a.latent / 32)
     unet_peak = F16_MFMA_PEAK_TF / 3.0 if a.unet_precision == "f16x2" else FP32_MFMA_PEAK_TF      # algorithmic flops / s
     roof_eval_us = max(UNET_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e9), flops_eval / (unet_peak * 1e12)) * 1e6
-    # time the loops had the chip: phased = up to the last loop of each round; otherwise they overlap the grids
-    if a.schedule == "phased" and timeline and a.overlap_blocks:
-        loop_phase_ms = timeline[0]["loops_done_ms"]         # only the first round's loops have the chip to themselves
-    elif a.schedule == "phased" and timeline:
-        prev, loop_phase_ms = 0.0, 0.0
-        for m in timeline:
-            loop_phase_ms += m["loops_done_ms"] - prev
-            prev = m["grids_done_ms"]
-    else:
-        loop_phase_ms = None
     streamed_gbs = loops * T * UNET_WEIGHT_BYTES / ((loop_phase_ms * 1e-3) if loop_phase_ms else elapsed) / 1e9
     if a.schedule == "phased" and a.overlap_blocks:
         phased_txt = (f"overlapped rounds: the reverse loops of round r + 1 ({n_chains} wide loops at once, up to {loop_batches} steps each, conv kernel in its wide "
@@ -593,6 +692,13 @@ def main():
              "overlap": (f"{n_chains} reverse loops of different steps in flight (own stream + context each, split-K sized for {a.loop_cus} CUs) next to the grids "
                          f"of an older step on {a.decoder_blocks} of the 256 CUs"),
              "sequential": "none (loop then grids, one stream)"}[a.schedule]
+    # what is in flight on one GPU in this schedule (say it next to shapes_per_gpu)
+    if a.schedule == "phased":
+        round_steps = min(a.steps, n_chains * loop_batches)
+        latents_per_loop_cfg = B * min(loop_batches, max(1, -(-round_steps // n_chains)))
+        shapes_in_flight = B * round_steps
+    else:
+        latents_per_loop_cfg, shapes_in_flight = B, B * (n_chains + 1 if a.schedule == "overlap" else 1)
     out = {
         "metric": "shapes/sec end-to-end (1000-step uncond, 512^3 UDF) at 1/2/4/8 GPU",
         "value": shapes / elapsed, "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -605,7 +711,9 @@ def main():
                                   f"W-trace: reverse loops + decoder over the {N}^3 thin-shell query lists of a trained-model-like field")
                                + (", end point E1 (grids resident in HBM)" if a.endpoint == "e1" else ", end point E2 (through marching cubes: every mesh finished inside the timed region)"),
                    "baseline_config": a.config, "endpoint": a.endpoint,
-                   "shapes_per_gpu": B, "resolution": N, "diffusion_steps": T, "latent": a.latent,
+                   "shapes_per_gpu": B, "shapes_per_gpu_means": "shapes per step and GPU; the schedule keeps `shapes_in_flight` shapes of consecutive steps in flight on one GPU",
+                   "latents_per_loop": latents_per_loop_cfg, "loops_in_flight": n_chains, "shapes_in_flight": shapes_in_flight,
+                   "resolution": N, "diffusion_steps": T, "latent": a.latent,
                    "decoder_fwd_queries_per_shape": n_fwd, "decoder_grad_queries_per_shape": n_grad,
                    "decoder_precision": a.decoder_precision, "unet_precision": a.unet_precision,
                    "fp16_range_saturations": sat,
@@ -615,25 +723,26 @@ def main():
         "roofline": {"kernel": kname, "bound": "mfma",
                      "achieved": algorithmic, "peak": peak, "unit": "TFLOP/s", "frac": algorithmic / peak,
                      "traffic": (pmc or {}).get("decoder_fwd_hbm_bytes_per_launch"),
-                     "traffic_from": "committed profile (not a counter of this run): " + str((pmc or {}).get("source")),
+                     "traffic_from": pmc_note,
                      "algorithmic_bytes_per_launch": 16.0 * fwd_total / max(fwd_launches, 1),
                      "launches": fwd_launches, "avg_launch_ms": fwd_ms / max(fwd_launches, 1),
                      "flop_per_point": FWD_FLOP,
                      "issued_tflops": (3.0 if f16 else 1.0) * algorithmic, "issued_frac": (3.0 if f16 else 1.0) * algorithmic / peak,
                      "cus": (f"{a.decoder_blocks} of 256 while loops are in flight, 256 for the last round; peak is the whole chip's")
                             if a.schedule == "overlap" else "256"},
-        "roofline_loop": {"kernel": "conv2_kernel x84 + attn_kernel x16 + 2 step kernels per denoiser evaluation (hipGraph replay)",
+        "roofline_loop": {"kernel": "conv2_kernel x84 (the head's epilogue carries the posterior update and the loop counter) + attn_kernel x16 per denoiser evaluation (hipGraph replay)",
                           "bound": "hbm", "achieved": streamed_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": streamed_gbs / HBM_PEAK_GBS,
                           "traffic": (pmc or {}).get("unet_eval_hbm_bytes"),
-                          "traffic_from": "committed profile (not a counter of this run)",
+                          "traffic_from": pmc_note,
                           "algorithmic_bytes_per_evaluation": UNET_WEIGHT_BYTES,
                           "latents_per_loop": lat_per_loop, "loops_in_flight": n_chains, "loops": loops,
                           "roof_us_per_evaluation": roof_eval_us,
                           "one_loop_alone_ms_per_evaluation": loop_alone_ms / T,
                           "one_loop_alone_frac": roof_eval_us * 1e-3 / (loop_alone_ms / T),
                           "one_loop_alone_us_per_evaluation_and_latent": loop_alone_ms / T * 1e3 / lat_per_loop,
-                          "in_schedule_ms_per_evaluation": loop_ms / max(loops, 1) / T},
+                          "in_schedule_ms_per_evaluation": loop_ms / max(loops, 1) / T,
+                          "in_schedule_us_per_evaluation_and_latent": (loop_phase_ms * 1e3 / (T * B * a.steps)) if loop_phase_ms else None},
         "time_share": ({"loops_alone_on_chip_ms": loop_phase_ms, "grids_ms": elapsed * 1e3 - loop_phase_ms,
                         "loops_frac": loop_phase_ms / (elapsed * 1e3)} if loop_phase_ms is not None else None),
         "breakdown_ms_per_step": {"reverse_loop_latency": loop_ms / max(loops, 1), "decoder_fwd": fwd_ms / a.steps,
@@ -642,6 +751,10 @@ def main():
     }
     if per_rank is not None:
         out["per_rank"] = per_rank
+    if strict is not None:
+        out["strict_c3"] = strict
+    if trace_e2 is not None:
+        out["trace_e2"] = trace_e2
     if w_trace is not None:
         per_shape_ms = w_trace["decoder_fwd_ms_per_shape"] + w_trace["decoder_fwd_bwd_ms_per_shape"]
         w_trace["note"] = ("decoder kernels alone on all CUs, values discarded; with this occupancy a step's grids take "
@@ -649,6 +762,8 @@ def main():
         out["w_trace"] = w_trace
     if mesh_stats is not None:
         out["e2"] = {"status": "timed", "value": shapes / elapsed, "unit": "shapes/s", **mesh_stats}
+    elif trace_e2 is not None:
+        out["e2"] = {"status": "see trace_e2 (timed, trained-model-like field); the synthetic decoder's own field has almost no surface to mesh"}
     elif not a.no_e2:
         out["e2"] = e2_estimate(a, elapsed, shapes, world)
     if not a.no_cpu_baseline and world == 1:          # a stated baseline of the N=1 line only

@@ -108,23 +108,26 @@ def conditioning_vectors(a, count):
     from PIL import Image
     from surfd_amd import preprocess
     from surfd_amd.clip_towers import ClipTowers, SimpleTokenizer
-    towers = ClipTowers.from_file(a.clip_path).to("cuda")
+    dev = "cuda" if torch.cuda.is_available() else "cpu"      # the towers are plain torch modules evaluated once per request
+    towers = ClipTowers.from_file(a.clip_path).to(dev)
     if a.mode == "text":
+        if not a.prompt:
+            raise SystemExit("text mode with --clip_path needs --prompt")
         tok = SimpleTokenizer(a.bpe_path)
-        emb = towers.encode_text(tok.tokenize([a.prompt] * count).cuda())                 # models/mdm.py:86-89, hoisted out of the loop
+        emb = towers.encode_text(tok.tokenize([a.prompt] * count).to(dev))                # models/mdm.py:86-89, hoisted out of the loop
     elif a.mode == "image":
+        if not a.image_path or not a.mask_path:
+            raise SystemExit("image mode with --clip_path needs --image_path AND --mask_path (sample/generate_image.py:92-107 crops the "
+                             "photo around its mask before the image tower sees it)")
         img = np.array(Image.open(a.image_path).convert("RGB"))
         mask = np.array(Image.open(a.mask_path).convert("1"))
         clean, _ = preprocess.masked_crops(img, mask, r=0.7)                              # sample/generate_image.py:92-107
-        emb = towers.encode_image(preprocess.clip_image_tensor(clean, 224)[None].cuda()).expand(count, -1)
+        emb = towers.encode_image(preprocess.clip_image_tensor(clean, 224)[None].to(dev)).expand(count, -1)
     else:
-        sk = Image.open(a.sketch_path).convert("RGB")                                      # sample/generate_sketch.py:70-80 (_transform: centre crop)
-        w, h = sk.size
-        side = min(w, h, 224) if min(w, h) >= 224 else min(w, h)
-        sk = sk.crop(((w - 224) // 2, (h - 224) // 2, (w - 224) // 2 + 224, (h - 224) // 2 + 224))
-        t = torch.from_numpy(np.asarray(sk, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
-        t = (t - torch.tensor(preprocess.CLIP_MEAN).view(3, 1, 1)) / torch.tensor(preprocess.CLIP_STD).view(3, 1, 1)
-        emb = towers.encode_image(t[None].cuda()).expand(count, -1)
+        if not a.sketch_path:
+            raise SystemExit("sketch mode with --clip_path needs --sketch_path")
+        t = preprocess.sketch_clip_tensor(Image.open(a.sketch_path), 224)                 # sample/generate_sketch.py:30-37, 75-81
+        emb = towers.encode_image(t[None].to(dev)).expand(count, -1)
     return emb.float().contiguous().cpu()
 
 

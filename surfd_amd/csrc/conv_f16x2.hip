@@ -56,7 +56,8 @@ struct Conv2Args {
     int nseg;
     const _Float16 *whf;   // [ntiles][KS16][2 planes][64 lanes][8]
     int KS16;
-    const float *sc;       // {SC, 1/SC}
+    const float *sc;       // {SC, 1/SC} on the device (weight preparation); the kernel takes 1/SC by value:
+    float inv_sc;          // a dependent scalar load in front of everything else cost ~1 us per workgroup
     const float *bias;     // [Cout]
     const float *emb;      // emb[b * emb_bstride + co] or null
     long emb_bstride;
@@ -78,11 +79,16 @@ struct Conv2Args {
     const int *step_ptr;   // device loop counter (embedding rows advance by emb_step_stride per step) or null
     long emb_step_stride;
     unsigned *sat;         // saturation counter
+    LoopFuse lf;           // head convolution inside the graph-replayed loop: posterior update + loop-counter advance in the epilogue
+    int lf_on;
     long long *dbg;        // -DSURFD_C2_STAMPS builds: 16 phase stamps (100 MHz ticks) of workgroup 0
 };
 
-constexpr int C2_U = 4;    // k16 steps per ring stage
-constexpr int C2_D = 2;    // ring stages (16 x 1 KB fragments in flight per wave); 3 does not fit 256 VGPRs (2 workgroups per CU)
+constexpr int C2_D = 2;    // ring stages; with 4 k16 steps per stage 16 x 1 KB fragments are in flight per wave (3 stages do not fit 256 VGPRs)
+#ifndef SURFD_C2_LEAN_WAVES
+#define SURFD_C2_LEAN_WAVES 3          // waves per SIMD (= workgroups per CU) the lean form is compiled for: 3 -> 168 VGPRs, no spills
+#endif
+constexpr int C2_PLANE_LEAN = 10112;   // halfs per fp16 plane of the slab in the lean form: 2 planes + flag = 40 464 B, four workgroups per CU
 
 __device__ __forceinline__ float silu2(float v) { return v * __frcp_rn(1.f + __expf(-v)); }
 
@@ -94,14 +100,22 @@ __device__ __forceinline__ void lds_bar() {
 
 // VEC: float4 registers a thread holds while staging its channel (8: operand rows of 4..32 positions,
 // nb * Lin <= 32; 16: 64 positions).  PREF: request the next K block's operand before the current MFMAs.
-template <int VEC, bool PREF, bool WT = false>
-__global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args A) {
+// LEAN (wide form only): the same arithmetic in half the registers and 40 KB of LDS, so that FOUR workgroups share a CU
+//       (16 waves): a workgroup's life is a chain of latencies (operand fetch, GroupNorm exchange, weight stream, split-K
+//       hand-off) around 1.7 us of matrix time, and with two workgroups per CU the CU idles through most of it (measured:
+//       one workgroup per CU instead of two = 1.4-1.5x the loop time).  What it gives up: the weight ring is two k16 steps
+//       per stage instead of four, the GroupNorm exchange arrays alias the (not yet written) slab — one more barrier —
+//       and the epilogue operands are requested after the K loop instead of at kernel start.
+template <int VEC, bool PREF, bool WT = false, bool LEAN = false>
+__global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 2)) void conv2_kernel(Conv2Args A) {
+    static_assert(!LEAN || (WT && VEC == 8 && !PREF), "lean form: wide decomposition, rows of <= 32 positions, no operand prefetch");
+    constexpr int C2_U = LEAN ? 2 : 4;    // k16 steps per ring stage
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
-    float *ex_mean = reinterpret_cast<float *>(lds_raw + A.off_ex);     // [VEC][256]
+    float *ex_mean = reinterpret_cast<float *>(lds_raw + (LEAN ? 0 : A.off_ex));     // [VEC][256]
     float *ex_m2 = ex_mean + VEC * 256;                                 // [VEC][256]
     float *gstat = ex_m2 + VEC * 256;                                   // [nb * groups][2]
-    float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag
+    float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag (lean form: the flag alone)
 
     const int tid = threadIdx.x, lane = tid & 63;
     // provably wave-uniform: everything derived from it (k-part, column tile, iteration ranges, weight bases) stays in SGPRs
@@ -168,9 +182,9 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     const int nblk0 = A.seg[0].nblk;
     const int nch = nblk0 + (A.nseg > 1 ? A.seg[1].nblk : 0);
     // the low fp16 plane of the slab sits PLANE halfs behind the high one: a compile-time LDS offset
-    constexpr int PLANE = VEC == 16 ? 18432 : 14336;
+    constexpr int PLANE = LEAN ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 14336);
     const int cs = A.cs;
-    const float inv_sc = A.sc[1];
+    const float inv_sc = A.inv_sc;
 
     // two accumulators: the two small cross terms (xl*wh, xh*wl) share one, the main term has its own; a third
     // would push the kernel over 256 VGPRs (2 workgroups per CU) and make the compiler spill a just-loaded value
@@ -202,7 +216,11 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     auto load_group = [&](f16x8 (&dst)[C2_U][2], const _Float16 *base, int it0, int it_last) {
 #pragma unroll
         for (int u = 0; u < C2_U; ++u) {
+#if defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 2      // developer aid: every fragment from one address (no weight stream)
+            const int it = 0 * (it0 + it_last);
+#else
             const int it = max(min(it0 + u, it_last), 0);
+#endif
             const gf16x8 *p = (const gf16x8 *)(base + (size_t)it * 1024);
             dst[u][0] = p[0];
             dst[u][1] = p[64];          // low plane: +512 halfs
@@ -242,9 +260,9 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
     // wait for the (HBM-resident) embedding rows in front of the first K block
     f32x4 pre_b[4], pre_e[4];
     float pre_r[16];
-    {
-        const float *embp = A.emb;                    // never null: the host points unused operands at the bias vector
-        if (A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;
+    const float *embp = A.emb;                        // never null: the host points unused operands at the bias vector
+    if (A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;   // scalar load, requested here, first used by request_epilogue
+    auto request_epilogue = [&]() {
         const int m = min(ct * 32 + (lane & 31), M - 1);
         const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
         const int cmax4 = ((A.Cout + 3) & ~3) - 4;     // last aligned float4 of the (4-padded) per-channel vectors
@@ -259,7 +277,8 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
                 pre_r[4 * q + k] = A.res[b * A.res_bstride + (long)co * A.res_cstride + l * A.res_lstride];
             }
         }
-    }
+    };
+    if constexpr (!LEAN) request_epilogue();
     bool saturated = false;
     C2_STAMP(1);
 
@@ -341,17 +360,29 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
                 }
                 lds_bar();
                 C2_STAMP_FIRST(3);
-                if (cok) {
-                    const int gq = c / gs;
+                // group mean / scale of every row this thread holds, in registers: in the lean form the exchange arrays
+                // (gstat included) alias the slab, so they must be dead — one more barrier — before the slab is written
+                float gmr[VEC], gscr[VEC];
+                {
+                    const int gq = min(c, blk - 1) / gs;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
                         const int i = j >> lv;
                         const int q = (i < nb) ? i * ng + gq : 0;
-                        const float gm = gstat[2 * q], gsc = ga * gstat[2 * q + 1];
+                        gmr[j] = gstat[2 * q]; gscr[j] = ga * gstat[2 * q + 1];
+                    }
+                }
+                if constexpr (LEAN) lds_bar();
+                if (cok) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float gm = gmr[j], gsc = gscr[j];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float w = (v[j][k] - gm) * gsc + be;
+#if !(defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 3)  // developer aid 3: no SiLU
                             if (act) w = silu2(w);
+#endif
                             v[j][k] = w;
                         }
                     }
@@ -422,9 +453,13 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
                         const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
                         const f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
                         const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + PLANE);
+#if defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 1      // developer aid: no matrix work (operands still fetched)
+                        acc_sm[0] += (float)a[u][1][0] + (float)bh[0]; acc_hh[0] += (float)a[u][0][0] + (float)bl[0];
+#else
                         acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_sm, 0, 0, 0);
                         acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
                         acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm, 0, 0, 0);
+#endif
                     }
                 }
             };
@@ -463,6 +498,7 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
             issue_operand(ch, v, ga, be);
         }
     }
+    if constexpr (LEAN) request_epilogue();      // round trip hidden behind the split-K hand-off (or the other workgroups of the CU)
     if (saturated) atomicAdd(A.sat, 1u);
     C2_STAMP(6);
 
@@ -503,7 +539,7 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int *flag = reinterpret_cast<int *>(red + 3 * 1024);
+        int *flag = reinterpret_cast<int *>(LEAN ? red : red + 3 * 1024);
         if (tid == 0) {
             const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (prev == A.KS - 1) ? 1 : 0;
@@ -538,7 +574,31 @@ __global__ __launch_bounds__(256, VEC == 16 ? 1 : 2) void conv2_kernel(Conv2Args
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = tile * 32 + frag_row(r, lane);
-            if (mok && co < A.Cout) A.out[b * A.out_bstride + (long)co * A.Lout + l] = acc[r] * inv_sc + ((pre_b[r >> 2][r & 3] + (A.has_emb ? pre_e[r >> 2][r & 3] : 0.f)) + (A.has_res ? pre_r[r] : 0.f));
+            if (mok && co < A.Cout) {
+                const float val = acc[r] * inv_sc + ((pre_b[r >> 2][r & 3] + (A.has_emb ? pre_e[r >> 2][r & 3] : 0.f)) + (A.has_res ? pre_r[r] : 0.f));
+                A.out[b * A.out_bstride + (long)co * A.Lout + l] = val;
+                if (A.lf_on) {
+                    // x0 prediction -> x_{t-1}, in place (this element of x is read and written by this thread only)
+                    const int k = *A.lf.step;
+                    const long n = (long)A.B * A.Cout * A.Lout, e = ((long)b * A.Cout + co) * A.Lout + l;
+                    const float xn = loop_update(A.lf.sampler, A.lf.clip, A.lf.eta, A.lf.tab + (long)k * 8, val, A.lf.x[e], A.lf.lp->noise[(long)(1 + k) * n + e]);
+                    A.lf.x[e] = xn;
+                    if (A.lf.lp->traj) A.lf.lp->traj[(long)k * n + e] = xn;
+                }
+            }
+        }
+    }
+    if (A.lf_on) {
+        // the last workgroup to get here advances the loop counter: every workgroup of this launch that reads it (above, and for
+        // the embedding row) has done so before it arrives
+        const int k = *A.lf.step;
+        __syncthreads();
+        if (tid == 0) {
+            const int prev = __hip_atomic_fetch_add(A.lf.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == A.nby * A.nrt - 1) {
+                __hip_atomic_store(A.lf.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.lf.step, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 #ifdef SURFD_C2_STAMPS
@@ -689,6 +749,10 @@ int conv2_finalize(surfd_unet *u, hipStream_t st) {
                            (const float *)sc, u->whf + c.whf_off);
         LAUNCH_CHECK();
     }
+    // the kernels take 1/SC by value (launch_conv2): one read-back per finalize
+    u->wsc_host.assign((size_t)u->n_sc * 4, 0.f);
+    HIP_TRY(hipMemcpyAsync(u->wsc_host.data(), u->wsc, u->wsc_host.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return SURFD_OK;
 }
 
@@ -742,11 +806,13 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     // wide form: one column tile per workgroup (M <= 32); layers whose single batch entry already spans two column
     // tiles (64 positions) stay in the latency form
     const bool wt = wide && A.Lout <= 32 && VEC == 8;
+    static const int lean_env = env_int("SURFD_CONV2_LEAN", 1);      // 0: the two-workgroups-per-CU wide kernel (A/B timing)
+    const bool lean = wt && lean_env;
     const int nb_cap = std::min({(VEC * 4) / Lin0, std::max(1, (wt ? 32 : 64) / A.Lout), 8});
     int nb = std::min(B, nb_cap);
     // one fp16 plane of the slab has a fixed size (the kernel addresses the low plane with an immediate): 28 KB
     // (36 KB for 64-long rows), i.e. <= 74 KB of LDS per workgroup so that two of them share a CU
-    const size_t plane_halfs = VEC == 16 ? 18432 : 14336;
+    const size_t plane_halfs = lean ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 14336);
     while (nb > 1 && (size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) --nb;
     if ((size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) return 1;
     if (nb * A.Lout > (wt ? 32 : 64)) return 1;
@@ -758,10 +824,14 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     // GroupNorm exchange area (staging) and k-part reduction scratch (after the last MFMA) are never live together
     A.off_ex = (int)lds;
     A.off_red = (int)lds;
-    lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
+    if (lean) lds += 16;      // the split-K flag; the GroupNorm exchange arrays alias the slab (2 x 8 KB + 2 KB <= 2 planes)
+    else lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
+    static const int lds_extra = env_int("SURFD_CONV2_LDS_EXTRA", 0);   // developer aid: fewer workgroups per CU (occupancy experiments)
+    lds += (size_t)lds_extra;
     if (lds > 160 * 1024) return 1;
     A.whf = u->whf + c.whf_off; A.KS16 = c.KS16;
     A.sc = u->wsc + (size_t)c.sc_idx * 4;
+    A.inv_sc = u->wsc_host[(size_t)c.sc_idx * 4 + 1];
     A.bias = u->vecs + c.bias_off;
     A.emb = A.bias; A.emb_bstride = 0; A.res = A.bias; A.res_bstride = 0; A.res_cstride = 1; A.res_lstride = 0;
     if (c.emb_off >= 0 && io.emb) {
@@ -785,7 +855,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     const int base = A.ntiles * A.nby;
     A.nrt = wt ? ceil_div(A.ntiles, 4) : A.ntiles;
     int KS = 1;
-    A.part_stride = 2 * 1024;
+    A.part_stride = wt ? 1024 : 2 * 1024;      // floats per partial tile: one column tile (wide form) or up to two
     if (wide) {
         // the K split is a function of the LAYER and of the handle's design batch only — never of B — so that a latent's
         // result does not depend on the width of the batch it rides in
@@ -793,7 +863,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         while (nbd > 1 && (size_t)nbd * A.Lsl * (max_blkp + 8) > plane_halfs) --nbd;
         const int based = A.nrt * ceil_div(u->wide_batch, nbd);
         if (nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / based)});
-        if ((size_t)KS * base * A.part_stride > u->part_floats || base > 8192)
+        if ((size_t)KS * base * A.part_stride > u->part_floats || (long)A.nby * A.nrt > 8192)
             SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv (wide form): batch of %d needs more split-K scratch than the handle holds", B);
     } else {
         if (base < ks_min_base && nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / base)});
@@ -802,6 +872,12 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.KS = KS;
     A.part = u->part; A.counters = u->counters;
     A.sat = u->sat;
+    if (io.lf && c.dst.buf == -3) {
+        // needs one epilogue per (batch chunk, row group) — true for every decomposition — and contiguous [B, Cout, L] output
+        if (io.ext_out_bs != (long)c.Cout * A.Lout) SURFD_FAIL(SURFD_ERR_ARG, "conv: fused posterior update needs a contiguous head output");
+        A.lf = *io.lf; A.lf_on = 1;
+        if (io.lf_done) *io.lf_done = true;
+    }
     A.dbg = nullptr;
     if (u->dbg && u->dbg_launch < 4096) {
         A.dbg = u->dbg + (size_t)(u->dbg_launch++) * 16;
@@ -816,7 +892,8 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     dim3 grid((unsigned)(G < 8 ? G * A.nby : 8 * ceil_div(G, 8) * A.nby));
     static const int pref = env_int("SURFD_CONV2_PREF", 0);      // operand prefetch across K blocks: measured 1.472 (on) vs 1.442 ms (off) per evaluation
     static const int wpref = env_int("SURFD_CONV2_WIDE_PREF", 0);
-    if (wt && wpref) hipLaunchKernelGGL((conv2_kernel<8, true, true>), grid, dim3(256), lds, st, A);
+    if (lean) hipLaunchKernelGGL((conv2_kernel<8, false, true, true>), grid, dim3(256), lds, st, A);
+    else if (wt && wpref) hipLaunchKernelGGL((conv2_kernel<8, true, true>), grid, dim3(256), lds, st, A);
     else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true>), grid, dim3(256), lds, st, A);
     else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
     else if (pref) hipLaunchKernelGGL((conv2_kernel<8, true>), grid, dim3(256), lds, st, A);
@@ -832,6 +909,7 @@ int conv2_set_attributes() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     return SURFD_OK;
 }
 

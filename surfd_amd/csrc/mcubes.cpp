@@ -690,7 +690,8 @@ int surfd_mc_scratch_create(int n, surfd_mc_scratch **out) {
     std::unique_ptr<surfd_mc_scratch> sc(new surfd_mc_scratch());
     const size_t v = (size_t)n * n * n;
     sc->n = n;
-    sc->far_value = 1.0f;                                        // any value above max_thr = 3.48 / (n - 1)
+    // any value above the band threshold max_thr = 3.48 / (n - 1) (1.0 would sit INSIDE it for n <= 4)
+    sc->far_value = std::max(1.0f, 2.0f * 3.48f / (float)(n - 1));
     sc->udf = (float *)malloc(v * sizeof(float));
     sc->grads = (float *)calloc(v * 3, sizeof(float));          // zero pages: materialised only where a band touches them
     sc->state = (unsigned char *)calloc(v, 1);

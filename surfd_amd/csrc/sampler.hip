@@ -12,6 +12,7 @@
 #include "common.h"
 #include "unet_api.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace surfd {
 
@@ -90,12 +91,6 @@ int surfd_ddim_step(const float *x_t, const float *x0, const float *z, float sqr
 // embedding rows (unet.hip), the coefficient row, the noise row and the trajectory slot.
 namespace surfd {
 
-struct LoopParams {          // device-resident; refreshed per call so the cached graph is pointer-free
-    const float *noise;      // [T'+1, n]
-    float *traj;             // [T', n] or null
-    int T;
-};
-
 // one row per loop iteration k (t index i = T'-1-k): DDPM {c1, c2, logvar, nonzero} / DDIM {sra, srm1, ab, abp, nonzero}
 __global__ void loop_step_kernel(int sampler, int clip, float eta, const float *tab, const LoopParams *lp,
                                  const int *step_ptr, float *x, const float *x0, long n) {
@@ -104,22 +99,7 @@ __global__ void loop_step_kernel(int sampler, int clip, float eta, const float *
     const float *z = lp->noise + (long)(1 + k) * n;
     float *tr = lp->traj ? lp->traj + (long)k * n : nullptr;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        float xs = x0[e];
-        if (clip) xs = fminf(fmaxf(xs, -1.f), 1.f);
-        float out;
-        if (sampler == 0) {
-            const float mean = __fadd_rn(__fmul_rn(row[0], xs), __fmul_rn(row[1], x[e]));
-            const float sd = expf(__fmul_rn(0.5f, row[2]));
-            out = __fadd_rn(mean, __fmul_rn(__fmul_rn(row[3], sd), z[e]));
-        } else {
-            const float sra = row[0], srm1 = row[1], ab = row[2], abp = row[3];
-            const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(sra, x[e]), xs), srm1);
-            const float sigma = __fmul_rn(__fmul_rn(eta, __fsqrt_rn(__fdiv_rn(__fsub_rn(1.f, abp), __fsub_rn(1.f, ab)))),
-                                          __fsqrt_rn(__fsub_rn(1.f, __fdiv_rn(ab, abp))));
-            const float mean = __fadd_rn(__fmul_rn(xs, __fsqrt_rn(abp)),
-                                         __fmul_rn(__fsqrt_rn(__fsub_rn(__fsub_rn(1.f, abp), __fmul_rn(sigma, sigma))), eps));
-            out = __fadd_rn(mean, __fmul_rn(__fmul_rn(row[4], sigma), z[e]));
-        }
+        const float out = loop_update(sampler, clip, eta, row, x0[e], x[e], z[e]);
         x[e] = out;
         if (tr) tr[e] = out;
     }
@@ -156,7 +136,7 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     if (rc) return rc;
     LoopState *ls = unet_loop_state(u);
     if (!ls->step_ctr) {
-        HIP_TRY(hipMalloc((void **)&ls->step_ctr, sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&ls->step_ctr, 2 * sizeof(int)));
         HIP_TRY(hipMalloc(&ls->params, sizeof(LoopParams)));
     }
     if ((size_t)n > ls->cap) {
@@ -183,7 +163,7 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     LoopParams lp{noise, traj, T};
     HIP_TRY(hipMemcpyAsync(ls->tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ls->params, &lp, sizeof(lp), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ls->step_ctr, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(ls->step_ctr, 0, 2 * sizeof(int), st));
     HIP_TRY(hipMemcpyAsync(ls->x, noise, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));        // host staging buffers above go out of scope; also quiesces before capture
     // ---- (re)capture one iteration if the shape of the step changed ---------------------------
@@ -196,14 +176,18 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     if (memcmp(key, ls->key, sizeof(key)) != 0) {
         if (ls->exec) { (void)hipGraphExecDestroy(ls->exec); ls->exec = nullptr; }
         if (ls->graph) { (void)hipGraphDestroy(ls->graph); ls->graph = nullptr; }
-        // dry run outside capture: sizes the workspace (allocations are illegal while capturing)
+        // dry run outside capture: sizes the workspace (allocations are illegal while capturing); without the fused
+        // posterior update, which would advance the state
         if ((rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, st, ls->step_ctr))) return rc;
         HIP_TRY(hipStreamSynchronize(st));
+        const LoopFuse lf{ls->tab, (const LoopParams *)ls->params, ls->x, ls->step_ctr, ls->step_ctr + 1, cfg->sampler, cfg->clip_denoised, cfg->eta};
+        bool fused = false;
         if (!ls->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&ls->cap_stream, hipStreamNonBlocking));
         hipStream_t cs = ls->cap_stream;
         HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, cs, ls->step_ctr);
-        if (!rc) {
+        static const bool fuse_env = !(getenv("SURFD_LOOP_FUSE") && atoi(getenv("SURFD_LOOP_FUSE")) == 0);   // 0: separate step kernels (A/B timing)
+        rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, cs, ls->step_ctr, fuse_env ? &lf : nullptr, &fused);
+        if (!rc && !fused) {
             hipLaunchKernelGGL(loop_step_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n, 256), 64)), dim3(256), 0, cs,
                                cfg->sampler, cfg->clip_denoised, cfg->eta, (const float *)ls->tab,
                                (const LoopParams *)ls->params, (const int *)ls->step_ctr, ls->x, (const float *)ls->x0, n);

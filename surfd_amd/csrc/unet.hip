@@ -1167,9 +1167,9 @@ struct Resolved { float *ptr; long bstride; };
 // Launch one planned convolution.  `B` batch entries, operand length Lseg(ds) = ds ? L/ds : 1.
 int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext_in[2], const long ext_in_bs[2],
                 const int ext_bmod[2], float *ext_out, long ext_out_bs, const float *emb, long emb_bs, hipStream_t st,
-                const int *step_ptr = nullptr) {
+                const int *step_ptr = nullptr, const LoopFuse *lf = nullptr, bool *lf_done = nullptr) {
     if (u->precision == 1 && c.f16_ok && (u->dbg_only < 0 || u->dbg_only == c.id)) {
-        const ConvLaunchIO io{ext_in[0], ext_in_bs[0], ext_out, ext_out_bs, emb, emb_bs, step_ptr};
+        const ConvLaunchIO io{ext_in[0], ext_in_bs[0], ext_out, ext_out_bs, emb, emb_bs, step_ptr, lf, lf_done};
         const int r2 = launch_conv2(u, c, B, L, io, st);
         if (r2 <= 0) return r2;          // launched (0) or failed (< 0); 1 = shape not covered -> fp32 kernel below
     }
@@ -1259,7 +1259,10 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     // the publish/acquire hand-off costs ~8 us: only worth it when a workgroup would otherwise stream
     // more than ~192 KB of weights on its own
     static const int nosplit_env = getenv("SURFD_CONV_NOSPLIT") ? 1 : 0;     // developer aid
-    if (!nosplit_env && ntiles * nby < 192 && work * 128 > 192 * 1024) ks_target = std::min(16, ceil_div(256, ntiles * nby));
+    // (wide form, Linear layers: the K chunking follows the handle's design batch, never B — an embedding row's summation
+    //  order must not depend on the batch it is computed in)
+    const int nby_k = fixed_rows ? ceil_div(u->wide_batch, chunk_rows) : nby;
+    if (!nosplit_env && ntiles * nby_k < 192 && work * 128 > 192 * 1024) ks_target = std::min(16, ceil_div(256, ntiles * nby_k));
     const long work_per_slice = ceil_div<long>(work, ks_target);
     int cs_max = 0, nchunks = 0;
     for (int s = 0; s < c.nseg; ++s) {
@@ -1401,11 +1404,11 @@ long unet_workspace_generation(surfd_unet *u) { return u->ws_gen; }
 
 // one op of the denoiser body: x / out are the external input / output of the whole network
 static int run_op(surfd_unet *u, const Op &op, const float *x, float *out, int B, int L, const float *emb, hipStream_t st,
-                  const int *step_ptr) {
+                  const int *step_ptr, const LoopFuse *lf = nullptr, bool *lf_done = nullptr) {
     if (op.kind == 0) {
         const float *in[2] = {x, x}; const long bs[2] = {(long)u->cfg.in_channels * L, (long)u->cfg.in_channels * L};
         const int bm[2] = {0, 0};
-        return launch_conv(u, op.conv, B, L, in, bs, bm, out, (long)u->cfg.out_channels * L, emb, u->emb_total, st, step_ptr);
+        return launch_conv(u, op.conv, B, L, in, bs, bm, out, (long)u->cfg.out_channels * L, emb, u->emb_total, st, step_ptr, lf, lf_done);
     }
     const AttnPlan &a = op.attn;
     const int T = L / a.ds, heads = u->cfg.num_heads, d = a.C / heads;
@@ -1422,7 +1425,7 @@ static int run_op(surfd_unet *u, const Op &op, const float *x, float *out, int B
 }
 
 int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st,
-                          const int *step_ptr) {
+                          const int *step_ptr, const LoopFuse *lf, bool *lf_done) {
     if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
     if (row0 < 0 || row0 + (u->emb_shared ? 1 : B) > u->emb_rows) SURFD_FAIL(SURFD_ERR_STATE, "unet: embedding rows [%d,%d) not prepared", row0, row0 + B);
     int max_ds = 1;
@@ -1432,7 +1435,7 @@ int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, i
     if (rc) return rc;
     const float *emb = u->emb_table + (size_t)row0 * u->emb_total;
     for (auto &op : u->ops)
-        if ((rc = run_op(u, op, x, out, B, L, emb, st, step_ptr))) return rc;
+        if ((rc = run_op(u, op, x, out, B, L, emb, st, step_ptr, lf, lf_done))) return rc;
     return SURFD_OK;
 }
 

@@ -79,6 +79,7 @@ struct surfd_unet {
     // f16x2 conv path (conv_f16x2.hip)
     _Float16 *whf = nullptr; size_t whf_halfs = 0;     // split-fp16 weight planes, fragment-major for the 32x32x16 MFMA
     float *wsc = nullptr; int n_sc = 0;                // per-layer power-of-two weight scale
+    std::vector<float> wsc_host;                       // host copy of wsc (the conv kernel takes 1/SC by value)
     unsigned *sat = nullptr;                           // device counter: workgroups that clamped an operand to the fp16 range
     int wide_batch = 0;                                // > 0: wide form of the f16x2 conv kernel, K split designed for this batch (surfd_unet_set_wide)
     int cu_budget = 256;                               // CUs this context's launches can count on (split-K sizing)
@@ -100,6 +101,8 @@ struct ConvLaunchIO {
     float *ext_out; long ext_out_bs;         // external result  (View.buf == -3)
     const float *emb; long emb_bs;           // embedding rows of this evaluation (nullable)
     const int *step_ptr;                     // device loop counter (nullable)
+    const LoopFuse *lf = nullptr;            // posterior update in the epilogue of the head convolution (nullable)
+    bool *lf_done = nullptr;                 // set when the launch took it over
 };
 int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunchIO &io, hipStream_t st);
 }  // namespace surfd

@@ -226,6 +226,8 @@ class BandMesher:
         import torch
         self.n, self.keep = int(n), keep
         self.max_thr = band_threshold(n)
+        capacity = max(1, min(int(capacity), self.n ** 3))     # surfd_band_create rejects more than N^3 (resolutions below 128)
+        self.capacity = capacity
         L = N.lib()
         self._free, self._work = queue.Queue(), queue.Queue()
         self._handles = []
@@ -278,7 +280,8 @@ class BandMesher:
         self._st = {"shapes": 0, "band_voxels": 0, "wait_and_copy_s": 0.0, "mesh_s": 0.0, "vertices": 0, "faces": 0}
 
     def submit(self, udf, grads, tag=None) -> None:
-        import torch
+        if self.errors:                                        # e.g. a band larger than `capacity`, seen by a worker at fetch time:
+            raise self.errors[0]                               # fail at the next submit, not after the whole run
         h = self._free.get()                                   # back-pressure: at most `slots` shapes between GPU and mesher
         N.check(N.lib().surfd_band_compact(h, N.ptr(udf), N.ptr(grads), C.c_float(self.max_thr), N.stream()))
         self._work.put((h, tag))

@@ -335,11 +335,13 @@ class PhasedPipeline:
                 threads, results, errors = pending
                 for t in threads:
                     t.join()
+                pending = None                              # joined; `finally` must only see rounds that are still running
                 if errors:
+                    errors[0].other_worker_errors = errors[1:]        # every failed loop worker of the round stays reachable
                     raise errors[0]
                 nxt = None
                 if overlap and r + 1 < len(plan):
-                    nxt = start_round(plan[r + 1][1])       # the next round's loops go next to this round's grids
+                    nxt = pending = start_round(plan[r + 1][1])   # the next round's loops go next to this round's grids
                 for c, _, _ in parts:
                     cur.wait_event(results[c][3])
                 if overlap:
@@ -354,7 +356,7 @@ class PhasedPipeline:
                     e1.record(cur)
                     marks.append((first, [results[c][3] for c, _, _ in parts], e1, sum(n for _, _, n in parts)))
                 if not overlap and r + 1 < len(plan):
-                    nxt = start_round(plan[r + 1][1])       # (their streams wait for this round's grids)
+                    nxt = pending = start_round(plan[r + 1][1])   # (their streams wait for this round's grids)
                 pending = nxt
         finally:
             if pending is not None:

@@ -5,6 +5,8 @@ photo and its mask before the CLIP image tower sees them.
   crop_square(img, bbox, ...)     <- data_loaders/dataset.py:29-77   square crop around the box, edge-padded, 256 x 256
   masked_crops(img, mask, r)      <- sample/generate_image.py:92-107 the "clean" (object on black) and "comp" crops
   clip_image_tensor(img, n_px)    <- data_loaders/dataset.py:87-93 (_transform_rgb): ToTensor, Normalize, Resize
+  sketch_clip_tensor(img, n_px)   <- sample/generate_sketch.py:30-37 (_transform): Resize(n_px, BICUBIC) of the SHORT side,
+                                     CenterCrop(n_px), RGB, ToTensor, Normalize
 
 Host-side numpy / PIL, outside the hot path.  mask2bbox / crop_square / masked_crops are pinned by fixtures made with the
 reference's own functions (tests/golden/g15_image_preprocess.npz); the final Resize is torchvision's in the reference
@@ -70,3 +72,42 @@ def clip_image_tensor(img, n_px: int = 224):
     a = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
     a = (a - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
     return F.interpolate(a[None], size=(n_px, n_px), mode="bilinear", antialias=True, align_corners=False)[0]
+
+
+def resize_short_side(img, n_px: int):
+    """torchvision.transforms.Resize(n_px, BICUBIC) on a PIL image: the shorter side becomes n_px, the longer one
+    int(n_px * long / short) (torchvision's _compute_resized_output_size), through PIL's own bicubic filter — which is
+    what torchvision calls for PIL inputs."""
+    from PIL import Image
+    w, h = img.size
+    if (w <= h and w == n_px) or (h <= w and h == n_px):
+        return img
+    if w <= h:
+        nw, nh = n_px, int(n_px * h / w)
+    else:
+        nw, nh = int(n_px * w / h), n_px
+    return img.resize((nw, nh), Image.BICUBIC)
+
+
+def center_crop(img, n_px: int):
+    """torchvision.transforms.CenterCrop(n_px) on a PIL image: box at int(round((side - n_px) / 2)); an image smaller than
+    the crop is first padded with zeros, centred (left / top get the smaller half) like torchvision does."""
+    from PIL import Image
+    w, h = img.size
+    if w < n_px or h < n_px:
+        pl, pt = max((n_px - w) // 2, 0), max((n_px - h) // 2, 0)
+        canvas = Image.new(img.mode, (max(w, n_px), max(h, n_px)))
+        canvas.paste(img, (pl, pt))
+        img = canvas
+        w, h = img.size
+    top, left = int(round((h - n_px) / 2.0)), int(round((w - n_px) / 2.0))
+    return img.crop((left, top, left + n_px, top + n_px))
+
+
+def sketch_clip_tensor(img, n_px: int = 224):
+    """PIL image of any size / mode -> float32 [3, n_px, n_px], the sketch driver's transform
+    (sample/generate_sketch.py:30-37): resize (short side, bicubic) -> centre crop -> RGB -> [0, 1] -> CLIP normalisation."""
+    import torch
+    img = center_crop(resize_short_side(img, n_px), n_px).convert("RGB")
+    a = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+    return (a - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)

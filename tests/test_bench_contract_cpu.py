@@ -75,19 +75,30 @@ def test_cpu_model_is_reported(bench):
 
 
 def test_committed_traffic_is_what_the_tool_derives(tmp_path, bench):
-    """roofline.traffic comes from profiles/r03_pmc_traffic.json; that file must be exactly what tools/pmc_to_traffic.py
-    derives from the committed PMC summary (KiB units, FETCH_SIZE doubled on gfx950), not a hand-edited number."""
+    """roofline.traffic comes from the newest profiles/rNN_pmc_traffic.json; that file must be exactly what
+    tools/pmc_to_traffic.py derives from the committed PMC summary (KiB units, FETCH_SIZE doubled on gfx950), not a hand-edited
+    number — and bench.py quotes it only while the kernel sources it names are unchanged."""
+    import glob
+    import hashlib
     import json
     import subprocess
-    src = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+    src = newest.replace("_pmc_traffic.json", "_pmc_summary.json")
     out = tmp_path / "traffic.json"
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_to_traffic.py"), src, str(out)],
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_to_traffic.py"), os.path.relpath(src, ROOT), str(out)],
                           stdout=subprocess.DEVNULL, cwd=ROOT)
     derived = json.load(open(out))
-    committed = bench.committed_traffic()
+    on_disk = json.load(open(newest))
     for k, v in derived.items():
         if isinstance(v, float):
-            assert committed[k] == pytest.approx(v, rel=1e-12), k
+            assert on_disk[k] == pytest.approx(v, rel=1e-12), k
     summary = json.load(open(src))
     dec = [v for k, v in summary["fetch"].items() if "decoder_fwd8_kernel" in k][0]
-    assert committed["decoder_fwd_fetch_bytes_per_launch"] == pytest.approx(dec["FETCH_SIZE"] * 1024 * 2 / dec["dispatches"])
+    assert on_disk["decoder_fwd_fetch_bytes_per_launch"] == pytest.approx(dec["FETCH_SIZE"] * 1024 * 2 / dec["dispatches"])
+    prof, note = bench.committed_traffic()
+    named = on_disk.get("source_sha256")
+    fresh = bool(named) and all(hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest() == d for rel, d in named.items())
+    if fresh:
+        assert prof == on_disk and "unchanged" in note
+    else:
+        assert prof is None and ("stale" in note or "does not name" in note)

@@ -90,3 +90,51 @@ def test_sample_command_lines_take_the_reference_flags():
         assert callable(importlib.import_module(f"sample.generate_{m}").main)
     with pytest.raises(SystemExit, match="drives a 'no_cond' model"):
         sc.run("uncond", ["--model_path", "m.pt", "--cond_mode", "text"])
+
+
+@pytest.mark.parametrize("mode", ["text", "image", "sketch"])
+def test_conditioning_vectors_run_the_towers_on_the_reference_inputs(drv, tmp_path, monkeypatch, mode):
+    """The --clip_path branches of the driver (exercised by no test): PIL load -> the mode's
+    preprocessing -> tower, with seeded CLIP weights (none exist offline).  The expected vector is computed here from the same
+    building blocks, so a wrong crop / resize / missing mask shows up as a mismatch."""
+    import types
+    from PIL import Image
+    from surfd_amd import preprocess, synth
+    from surfd_amd import clip_towers as ct
+    towers = ct.ClipTowers(synth.synth_clip_state_dict(seed=16))
+    monkeypatch.setattr(ct.ClipTowers, "from_file", classmethod(lambda cls, path: towers))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    rng = np.random.default_rng(3)
+    a = types.SimpleNamespace(mode=mode, embedding=None, clip_path="clip.pt", synthetic=False, prompt=None, image_path=None,
+                              mask_path=None, sketch_path=None, bpe_path=None)
+    if mode == "sketch":
+        p = tmp_path / "sketch.png"
+        Image.fromarray(rng.integers(0, 256, (180, 300), dtype=np.uint8)).save(p)      # 300 x 180, single channel
+        a.sketch_path = str(p)
+        want = towers.encode_image(preprocess.sketch_clip_tensor(Image.open(p), 224)[None])
+    elif mode == "image":
+        img = rng.integers(0, 256, (200, 260, 3), dtype=np.uint8)
+        mask = np.zeros((200, 260), bool)
+        mask[40:150, 90:210] = True
+        pi, pm = tmp_path / "photo.png", tmp_path / "mask.png"
+        Image.fromarray(img).save(pi)
+        Image.fromarray(mask).save(pm)
+        a.image_path = str(pi)
+        with pytest.raises(SystemExit, match="mask_path"):
+            drv.conditioning_vectors(a, 1)                                              # the photo alone is not enough
+        a.mask_path = str(pm)
+        clean, _ = preprocess.masked_crops(img, mask, r=0.7)
+        want = towers.encode_image(preprocess.clip_image_tensor(clean, 224)[None])
+    else:
+        bpe = "/root/reference/CLIP/clip/bpe_simple_vocab_16e6.txt.gz"
+        if not os.path.exists(bpe):
+            pytest.skip("CLIP's BPE merges file is only present where the reference tree is")
+        a.bpe_path = bpe
+        with pytest.raises(SystemExit, match="prompt"):
+            drv.conditioning_vectors(a, 1)
+        a.prompt = "a dining chair"
+        want = towers.encode_text(ct.SimpleTokenizer(bpe).tokenize([a.prompt]))
+    got = drv.conditioning_vectors(a, 2)
+    assert got.shape == (2, 512) and got.dtype == torch.float32 and got.is_contiguous() and got.device.type == "cpu"
+    assert torch.equal(got[0], got[1])
+    np.testing.assert_allclose(got[0].numpy(), want[0].float().numpy(), rtol=1e-5, atol=1e-6)

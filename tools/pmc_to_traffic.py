@@ -47,6 +47,8 @@ out = {
     "unet_eval_fetch_bytes": unet_fetch / evals,
     "unet_eval_write_bytes": unet_write / evals,
 }
+if "source_sha256" in r:          # the kernel sources the counters were collected with (tools/profile_round.sh): bench.py quotes
+    out["source_sha256"] = r["source_sha256"]      # the profile only while they are unchanged
 out["decoder_fwd_hbm_bytes_per_launch"] = out["decoder_fwd_fetch_bytes_per_launch"] + out["decoder_fwd_write_bytes_per_launch"]
 out["unet_eval_hbm_bytes"] = out["unet_eval_fetch_bytes"] + out["unet_eval_write_bytes"]
 out["unet_fetch_over_algorithmic"] = out["unet_eval_fetch_bytes"] / WEIGHT_BYTES
