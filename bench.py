@@ -195,7 +195,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(T, B, n_fwd, n_grad, latent=32):
+def cpu_baseline(T, B, n_fwd, n_grad, latent=32, N=512):
     """The oracle (CPU restatement of the reference's op graph) timed on this host on a bounded
     sample of the same workload, scaled to shapes/s: a few denoiser steps at batch B, forward decoder
     queries and forward+backward queries at the two chunk sizes the reference scripts use (the faster is quoted)."""
@@ -231,12 +231,33 @@ def cpu_baseline(T, B, n_fwd, n_grad, latent=32):
     t0 = time.time()
     odec.sample_grads(f, pts[:4096], 4096)
     grad_rate = 4096 / (time.time() - t0)
-    per_shape = T * step_s / B + n_fwd / fwd_rate + n_grad / grad_rate
-    return {"value": 1.0 / per_shape, "unit": "shapes/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
-            "host_cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_it} denoiser steps at batch {B} ({step_s * 1e3:.0f} ms/step), 16384 decoder forward queries "
-                      f"(chunk {fwd_chunk}: {fwd_rate:.0f} pts/s), 4096 forward+backward queries (chunk 4096: {grad_rate:.0f} pts/s); "
-                      f"extrapolated to {T} steps + {n_fwd:.0f} fwd + {n_grad:.0f} grad queries per shape (grid bookkeeping excluded)"}
+    # grid bookkeeping (coordinates, masks, scatter of five refinement levels — everything of GridFiller except the field itself):
+    # the oracle's fill of the analytic thin-shell field at 256^3, scaled by 8 to the N^3 arrays of 512^3 (the field is a few
+    # elementwise ops; < 1 % of a shape either way)
+    from oracle import gridfiller as ogrid
+    ogrid.fill_grid(ogrid.analytic_field, 64, 2 ** 30)
+    t0 = time.time()
+    ogrid.fill_grid(ogrid.analytic_field, 256, 2 ** 30)
+    book_s = (time.time() - t0) * (N / 256.0) ** 3
+    per_shape = T * step_s / B + n_fwd / fwd_rate + n_grad / grad_rate + book_s
+    out = {"value": 1.0 / per_shape, "unit": "shapes/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
+           "host_cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n_it} denoiser steps at batch {B} ({step_s * 1e3:.0f} ms/step), 16384 decoder forward queries "
+                     f"(chunk {fwd_chunk}: {fwd_rate:.0f} pts/s), 4096 forward+backward queries (chunk 4096: {grad_rate:.0f} pts/s), one 256^3 "
+                     f"grid fill of an analytic field for the bookkeeping ({book_s:.2f} s per {N}^3 shape); "
+                     f"extrapolated to {T} steps + {n_fwd:.0f} fwd + {n_grad:.0f} grad queries per shape"}
+    # what ties this number to the reference itself: the oracle and the imported reference timed on the same cores of the build
+    # container (tools/cpu_ratio.py; the reference does not exist on the GPU box)
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_oracle_vs_reference.json")))
+        out["oracle_over_reference_time"] = r["headline_mix"]["oracle_over_reference"]
+        out["reference_equivalent_value"] = out["value"] * r["headline_mix"]["oracle_over_reference"]
+        out["oracle_vs_reference"] = (f"profiles/r04_cpu_oracle_vs_reference.json: on {r['threads']} threads of the build container the oracle takes "
+                                      f"{r['headline_mix']['oracle_over_reference']:.3f} x the reference's time on this op mix (per case: "
+                                      + ", ".join(f"{x['case'].split(',')[0]} {x['oracle_over_reference']:.2f}" for x in r["rows"]) + ")")
+    except (OSError, ValueError, KeyError):
+        out["oracle_vs_reference"] = "profiles/r04_cpu_oracle_vs_reference.json missing: ratio not recorded"
+    return out
 
 
 def analytic_field_gpu(c):
@@ -767,7 +788,7 @@ def main():
     elif not a.no_e2:
         out["e2"] = e2_estimate(a, elapsed, shapes, world)
     if not a.no_cpu_baseline and world == 1:          # a stated baseline of the N=1 line only
-        out["cpu_baseline"] = cpu_baseline(T, B, n_fwd, n_grad, a.latent)
+        out["cpu_baseline"] = cpu_baseline(T, B, n_fwd, n_grad, a.latent, N)
     print(json.dumps(out))
 
 

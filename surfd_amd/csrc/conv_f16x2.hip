@@ -72,6 +72,7 @@ struct Conv2Args {
     int off_ex, off_red;   // byte offsets of the GroupNorm exchange area / reduction scratch in LDS
     int ntiles, nby, KS;
     int nrt;               // row groups: ntiles (latency form) or ceil(ntiles / 4) (wide form)
+    int nhalf;             // wide form, 64 output positions: 2 = a workgroup owns one 32-column half of ONE sample (nby counts halves)
     unsigned magic_nby, magic_ks, magic_g;   // ceil(2^32 / d): x / d == umulhi(x, magic) for x < 2^16 (d = nby, KS, nrt * KS)
     float *part;           // split-K partial tiles [KS][nby][ntiles][part_stride]
     int part_stride;
@@ -79,8 +80,9 @@ struct Conv2Args {
     const int *step_ptr;   // device loop counter (embedding rows advance by emb_step_stride per step) or null
     long emb_step_stride;
     unsigned *sat;         // saturation counter
-    LoopFuse lf;           // head convolution inside the graph-replayed loop: posterior update + loop-counter advance in the epilogue
-    int lf_on;
+    const LoopFuse *lf;    // device; head convolution inside the graph-replayed loop (LF instantiations): posterior update +
+                           // loop-counter advance in the epilogue.  A pointer, and its own instantiation: the other 83 launches of an
+                           // evaluation must not carry a byte or a register of it
     long long *dbg;        // -DSURFD_C2_STAMPS builds: 16 phase stamps (100 MHz ticks) of workgroup 0
 };
 
@@ -106,13 +108,20 @@ __device__ __forceinline__ void lds_bar() {
 //       one workgroup per CU instead of two = 1.4-1.5x the loop time).  What it gives up: the weight ring is two k16 steps
 //       per stage instead of four, the GroupNorm exchange arrays alias the (not yet written) slab — one more barrier —
 //       and the epilogue operands are requested after the K loop instead of at kernel start.
-template <int VEC, bool PREF, bool WT = false, bool LEAN = false>
-__global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 2)) void conv2_kernel(Conv2Args A) {
+//       64-position layers in the wide form (L = 64 latents: configurations C4 / C5): a workgroup stages the whole 64-position row of
+//       ONE sample (GroupNorm needs it) and computes one 32-column half of it (A.nhalf = 2); with VEC = 16 the exchange arrays
+//       alias the slab as in the lean form, which keeps two such workgroups on a CU.
+template <int VEC, bool PREF, bool WT = false, bool LEAN = false, bool LF = false>
+__global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT ? 2 : 1) : 2)) void conv2_kernel(Conv2Args A) {
     static_assert(!LEAN || (WT && VEC == 8 && !PREF), "lean form: wide decomposition, rows of <= 32 positions, no operand prefetch");
-    constexpr int C2_U = LEAN ? 2 : 4;    // k16 steps per ring stage
+    // the register / LDS diet of the lean form, also applied to 64-position rows in the wide form (16 float4 of operand per
+    // thread: without it the kernel spills 77 registers at two workgroups per CU)
+    constexpr bool SLIM = LEAN || (WT && VEC == 16);
+    constexpr int C2_U = SLIM ? 2 : 4;    // k16 steps per ring stage
+    constexpr bool ALIAS = SLIM;          // GroupNorm exchange arrays inside the (not yet written) slab
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
-    float *ex_mean = reinterpret_cast<float *>(lds_raw + (LEAN ? 0 : A.off_ex));     // [VEC][256]
+    float *ex_mean = reinterpret_cast<float *>(lds_raw + (ALIAS ? 0 : A.off_ex));     // [VEC][256]
     float *ex_m2 = ex_mean + VEC * 256;                                 // [VEC][256]
     float *gstat = ex_m2 + VEC * 256;                                   // [nb * groups][2]
     float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag (lean form: the flag alone)
@@ -162,9 +171,12 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
             tile = min(tile, A.ntiles - 1);       // an idle wave streams the last tile's weights (valid addresses, same schedule) and discards the result
         }
     }
-    const int b0 = by * A.bchunk;
+    // 64 output positions in the wide form: `by` counts (sample, 32-column half) pairs; m_off = first column of this half
+    const bool halves = WT && A.nhalf == 2;
+    const int m_off = halves ? (by & 1) * 32 : 0;
+    const int b0 = (halves ? by >> 1 : by) * A.bchunk;
     const int nb = min(A.bchunk, A.B - b0);
-    const int M = nb * A.Lout;
+    const int M = halves ? 32 : nb * A.Lout;
     // latency form: 1 or 2 column tiles (host guarantees M <= 64), 4 or 2 waves share a column tile as k-parts;
     // wide form: one column tile (M <= 32), every wave runs the whole K slice for its own row tile
     const int nct = WT ? 1 : (M + 31) >> 5;
@@ -176,13 +188,14 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
     {
         int m = ct * 32 + (lane & 31);
         if (m >= M) m = 0;
+        m += m_off;
         colb = m >> A.log2Lout;
         coll = m & (A.Lout - 1);
     }
     const int nblk0 = A.seg[0].nblk;
     const int nch = nblk0 + (A.nseg > 1 ? A.seg[1].nblk : 0);
     // the low fp16 plane of the slab sits PLANE halfs behind the high one: a compile-time LDS offset
-    constexpr int PLANE = LEAN ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 14336);
+    constexpr int PLANE = LEAN ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 15360);
     const int cs = A.cs;
     const float inv_sc = A.inv_sc;
 
@@ -262,8 +275,19 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
     float pre_r[16];
     const float *embp = A.emb;                        // never null: the host points unused operands at the bias vector
     if (A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;   // scalar load, requested here, first used by request_epilogue
+    // head of a fused loop: the loop record, the iteration and its coefficient row are requested now — behind the operand and
+    // weight requests above — and first used in the epilogue
+    LoopFuse lfv;
+    int lfk = 0;
+    float lfrow[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (LF) {
+        lfv = *A.lf;
+        lfk = *lfv.step;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) lfrow[q] = lfv.tab[(long)lfk * 8 + q];
+    }
     auto request_epilogue = [&]() {
-        const int m = min(ct * 32 + (lane & 31), M - 1);
+        const int m = min(ct * 32 + (lane & 31), M - 1) + m_off;
         const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
         const int cmax4 = ((A.Cout + 3) & ~3) - 4;     // last aligned float4 of the (4-padded) per-channel vectors
 #pragma unroll
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
             }
         }
     };
-    if constexpr (!LEAN) request_epilogue();
+    if constexpr (!SLIM) request_epilogue();
     bool saturated = false;
     C2_STAMP(1);
 
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
                         gmr[j] = gstat[2 * q]; gscr[j] = ga * gstat[2 * q + 1];
                     }
                 }
-                if constexpr (LEAN) lds_bar();
+                if constexpr (ALIAS) lds_bar();
                 if (cok) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
@@ -498,7 +522,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
             issue_operand(ch, v, ga, be);
         }
     }
-    if constexpr (LEAN) request_epilogue();      // round trip hidden behind the split-K hand-off (or the other workgroups of the CU)
+    if constexpr (SLIM) request_epilogue();      // round trip hidden behind the split-K hand-off (or the other workgroups of the CU)
     if (saturated) atomicAdd(A.sat, 1u);
     C2_STAMP(6);
 
@@ -539,7 +563,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int *flag = reinterpret_cast<int *>(LEAN ? red : red + 3 * 1024);
+        int *flag = reinterpret_cast<int *>(ALIAS ? red : red + 3 * 1024);
         if (tid == 0) {
             const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (prev == A.KS - 1) ? 1 : 0;
@@ -568,8 +592,8 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
     C2_STAMP(8);
     // ---- epilogue ---------------------------------------------------------------------------------------
     if (owner) {
-        const int m = ct * 32 + (lane & 31);
-        const bool mok = m < M;
+        const int ml = ct * 32 + (lane & 31), m = ml + m_off;
+        const bool mok = ml < M;
         const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -577,27 +601,25 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? 1 : 
             if (mok && co < A.Cout) {
                 const float val = acc[r] * inv_sc + ((pre_b[r >> 2][r & 3] + (A.has_emb ? pre_e[r >> 2][r & 3] : 0.f)) + (A.has_res ? pre_r[r] : 0.f));
                 A.out[b * A.out_bstride + (long)co * A.Lout + l] = val;
-                if (A.lf_on) {
+                if constexpr (LF) {
                     // x0 prediction -> x_{t-1}, in place (this element of x is read and written by this thread only)
-                    const int k = *A.lf.step;
                     const long n = (long)A.B * A.Cout * A.Lout, e = ((long)b * A.Cout + co) * A.Lout + l;
-                    const float xn = loop_update(A.lf.sampler, A.lf.clip, A.lf.eta, A.lf.tab + (long)k * 8, val, A.lf.x[e], A.lf.lp->noise[(long)(1 + k) * n + e]);
-                    A.lf.x[e] = xn;
-                    if (A.lf.lp->traj) A.lf.lp->traj[(long)k * n + e] = xn;
+                    const float xn = loop_update(lfv.sampler, lfv.clip, lfv.eta, lfrow, val, lfv.x[e], lfv.lp->noise[(long)(1 + lfk) * n + e]);
+                    lfv.x[e] = xn;
+                    if (lfv.lp->traj) lfv.lp->traj[(long)lfk * n + e] = xn;
                 }
             }
         }
     }
-    if (A.lf_on) {
-        // the last workgroup to get here advances the loop counter: every workgroup of this launch that reads it (above, and for
-        // the embedding row) has done so before it arrives
-        const int k = *A.lf.step;
+    if constexpr (LF) {
+        // the last workgroup to get here advances the loop counter: every workgroup of this launch that reads it (above) has
+        // done so before it arrives
         __syncthreads();
         if (tid == 0) {
-            const int prev = __hip_atomic_fetch_add(A.lf.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int prev = __hip_atomic_fetch_add(lfv.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == A.nby * A.nrt - 1) {
-                __hip_atomic_store(A.lf.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(A.lf.step, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(lfv.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(lfv.step, lfk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -803,19 +825,24 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     }
     A.Lsl = max_lsl;
     const int VEC = Lin0 == 64 ? 16 : 8;
-    // wide form: one column tile per workgroup (M <= 32); layers whose single batch entry already spans two column
-    // tiles (64 positions) stay in the latency form
-    const bool wt = wide && A.Lout <= 32 && VEC == 8;
+    // wide form: one column tile per workgroup (M <= 32); a layer with 64 output positions (L = 64 latents) is computed as two
+    // 32-column halves of one sample per workgroup pair, each staging the sample's whole row
+    static const int split_env = env_int("SURFD_CONV2_WIDE64", 1);   // 0: 64-position layers stay in the latency form (A/B timing)
+    const bool split = wide && A.Lout == 64 && split_env;
+    const bool wt = wide && (A.Lout <= 32 || split);
     static const int lean_env = env_int("SURFD_CONV2_LEAN", 1);      // 0: the two-workgroups-per-CU wide kernel (A/B timing)
-    const bool lean = wt && lean_env;
-    const int nb_cap = std::min({(VEC * 4) / Lin0, std::max(1, (wt ? 32 : 64) / A.Lout), 8});
+    const bool fuse_head = io.lf && c.dst.buf == -3;                 // 80 workgroups, once per evaluation: keeps the 256-register form (no spills with the loop record live)
+    // lean form (three workgroups per CU) wherever one batch entry's slab fits its 20 KB planes
+    const bool lean = wt && VEC == 8 && lean_env && !fuse_head && (size_t)A.Lsl * (max_blkp + 8) <= (size_t)C2_PLANE_LEAN;
+    const int nb_cap = split ? 1 : std::min({(VEC * 4) / Lin0, std::max(1, (wt ? 32 : 64) / A.Lout), 8});
     int nb = std::min(B, nb_cap);
-    // one fp16 plane of the slab has a fixed size (the kernel addresses the low plane with an immediate): 28 KB
-    // (36 KB for 64-long rows), i.e. <= 74 KB of LDS per workgroup so that two of them share a CU
-    const size_t plane_halfs = lean ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 14336);
+    // one fp16 plane of the slab has a fixed size (the kernel addresses the low plane with an immediate): 30 KB
+    // (36 KB for 64-long rows), i.e. <= 78 KB of LDS per workgroup so that two of them share a CU
+    const size_t plane_halfs = lean ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 15360);
     while (nb > 1 && (size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) --nb;
     if ((size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) return 1;
-    if (nb * A.Lout > (wt ? 32 : 64)) return 1;
+    if (!split && nb * A.Lout > (wt ? 32 : 64)) return 1;
+    A.nhalf = split ? 2 : 1;
     A.bchunk = nb;
     A.cs = max_blkp + 8;
     A.plane = (int)plane_halfs;
@@ -824,7 +851,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     // GroupNorm exchange area (staging) and k-part reduction scratch (after the last MFMA) are never live together
     A.off_ex = (int)lds;
     A.off_red = (int)lds;
-    if (lean) lds += 16;      // the split-K flag; the GroupNorm exchange arrays alias the slab (2 x 8 KB + 2 KB <= 2 planes)
+    if (lean || (wt && VEC == 16)) lds += 16;      // the split-K flag; the GroupNorm exchange arrays alias the slab (2 x 8 (16) KB + 2 KB <= 2 planes)
     else lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
     static const int lds_extra = env_int("SURFD_CONV2_LDS_EXTRA", 0);   // developer aid: fewer workgroups per CU (occupancy experiments)
     lds += (size_t)lds_extra;
@@ -837,6 +864,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     if (c.emb_off >= 0 && io.emb) {
         A.emb = io.emb + c.emb_off; A.step_ptr = io.step_ptr;
         A.emb_bstride = u->emb_shared ? 0 : io.emb_bs; A.emb_step_stride = u->emb_shared ? io.emb_bs : (long)B * io.emb_bs;
+        if (u->emb_ingraph) { A.step_ptr = nullptr; A.emb_step_stride = 0; }      // the iteration's own [B][14112] rows (unet_forward_prepared)
         A.has_emb = 1;
     }
     if (c.res.buf != -1) {
@@ -845,7 +873,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     }
     { float *p; long bs; resolve(c.dst, c.ds_out, true, p, bs); A.out = p; A.out_bstride = bs; }
     A.ntiles = ceil_div(c.Cout, 32);
-    A.nby = ceil_div(B, nb);
+    A.nby = ceil_div(B, nb) * A.nhalf;
     // K slices over workgroups when (tiles x batch chunks) under-fills the chip: whole K blocks per slice
     const int nch = c.nblk[0] + (c.nseg > 1 ? c.nblk[1] : 0);
     static const int ks_fill_env = env_int("SURFD_CONV2_FILL", 0);
@@ -861,7 +889,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         // result does not depend on the width of the batch it rides in
         int nbd = std::min(u->wide_batch, nb_cap);
         while (nbd > 1 && (size_t)nbd * A.Lsl * (max_blkp + 8) > plane_halfs) --nbd;
-        const int based = A.nrt * ceil_div(u->wide_batch, nbd);
+        const int based = A.nrt * ceil_div(u->wide_batch, nbd) * A.nhalf;
         if (nch > 1) KS = std::min({nch, ks_max, std::max(1, ks_fill / based)});
         if ((size_t)KS * base * A.part_stride > u->part_floats || (long)A.nby * A.nrt > 8192)
             SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "conv (wide form): batch of %d needs more split-K scratch than the handle holds", B);
@@ -872,10 +900,10 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.KS = KS;
     A.part = u->part; A.counters = u->counters;
     A.sat = u->sat;
-    if (io.lf && c.dst.buf == -3) {
+    if (fuse_head) {
         // needs one epilogue per (batch chunk, row group) — true for every decomposition — and contiguous [B, Cout, L] output
         if (io.ext_out_bs != (long)c.Cout * A.Lout) SURFD_FAIL(SURFD_ERR_ARG, "conv: fused posterior update needs a contiguous head output");
-        A.lf = *io.lf; A.lf_on = 1;
+        A.lf = io.lf;
         if (io.lf_done) *io.lf_done = true;
     }
     A.dbg = nullptr;
@@ -892,7 +920,14 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     dim3 grid((unsigned)(G < 8 ? G * A.nby : 8 * ceil_div(G, 8) * A.nby));
     static const int pref = env_int("SURFD_CONV2_PREF", 0);      // operand prefetch across K blocks: measured 1.472 (on) vs 1.442 ms (off) per evaluation
     static const int wpref = env_int("SURFD_CONV2_WIDE_PREF", 0);
-    if (lean) hipLaunchKernelGGL((conv2_kernel<8, false, true, true>), grid, dim3(256), lds, st, A);
+    if (A.lf) {         // the head of a graph-replayed loop: same decompositions, posterior update in the epilogue
+        if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true, false, true>), grid, dim3(256), lds, st, A);
+        else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true, false, true>), grid, dim3(256), lds, st, A);
+        else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, false, false, true>), grid, dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((conv2_kernel<8, false, false, false, true>), grid, dim3(256), lds, st, A);
+    }
+    else if (lean) hipLaunchKernelGGL((conv2_kernel<8, false, true, true>), grid, dim3(256), lds, st, A);
+    else if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true>), grid, dim3(256), lds, st, A);
     else if (wt && wpref) hipLaunchKernelGGL((conv2_kernel<8, true, true>), grid, dim3(256), lds, st, A);
     else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true>), grid, dim3(256), lds, st, A);
     else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
@@ -910,6 +945,11 @@ int conv2_set_attributes() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     return SURFD_OK;
 }
 

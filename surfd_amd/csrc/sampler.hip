@@ -129,15 +129,20 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     const bool shared = !ctx && !cls;
     const int per_step = shared ? 1 : B;
     if ((long)T * per_step > 2000000) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "surfd_sample_loop: %d steps x %d samples of embedding rows", T, per_step);
-    std::vector<int64_t> t_rows((size_t)T * per_step);
+    // conditioned: the time part per step and the sample part per sample, the 22 per-ResBlock rows inside the graph
+    // (SURFD_EMB_TABLE=1 keeps round 3's [T' x B, 14112] table: A/B timing)
+    static const bool table_env = getenv("SURFD_EMB_TABLE") && atoi(getenv("SURFD_EMB_TABLE")) == 1;
+    const bool ingraph = !shared && !table_env;
+    std::vector<int64_t> t_rows((size_t)T * (ingraph ? 1 : per_step));
     for (int k = 0; k < T; ++k)
-        for (int b = 0; b < per_step; ++b) t_rows[(size_t)k * per_step + b] = cfg->timestep_map[T - 1 - k];
-    int rc = unet_prepare_embeddings(u, t_rows.data(), T * per_step, ctx, cls, B, st, shared);
+        for (int b = 0; b < (ingraph ? 1 : per_step); ++b) t_rows[(size_t)k * (ingraph ? 1 : per_step) + b] = cfg->timestep_map[T - 1 - k];
+    int rc = ingraph ? unet_prepare_loop_embeddings(u, t_rows.data(), T, ctx, cls, B, st)
+                     : unet_prepare_embeddings(u, t_rows.data(), T * per_step, ctx, cls, B, st, shared);
     if (rc) return rc;
     LoopState *ls = unet_loop_state(u);
     if (!ls->step_ctr) {
         HIP_TRY(hipMalloc((void **)&ls->step_ctr, 2 * sizeof(int)));
-        HIP_TRY(hipMalloc(&ls->params, sizeof(LoopParams)));
+        HIP_TRY(hipMalloc(&ls->params, sizeof(LoopParams) + sizeof(LoopFuse)));
     }
     if ((size_t)n > ls->cap) {
         if (ls->x) HIP_TRY(hipFree(ls->x));
@@ -163,6 +168,9 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     LoopParams lp{noise, traj, T};
     HIP_TRY(hipMemcpyAsync(ls->tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ls->params, &lp, sizeof(lp), hipMemcpyHostToDevice, st));
+    LoopFuse *lf_dev = reinterpret_cast<LoopFuse *>(static_cast<char *>(ls->params) + sizeof(LoopParams));
+    const LoopFuse lf{ls->tab, (const LoopParams *)ls->params, ls->x, ls->step_ctr, ls->step_ctr + 1, cfg->sampler, cfg->clip_denoised, cfg->eta};
+    HIP_TRY(hipMemcpyAsync(lf_dev, &lf, sizeof(lf), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(ls->step_ctr, 0, 2 * sizeof(int), st));
     HIP_TRY(hipMemcpyAsync(ls->x, noise, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));        // host staging buffers above go out of scope; also quiesces before capture
@@ -180,13 +188,12 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
         // posterior update, which would advance the state
         if ((rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, st, ls->step_ctr))) return rc;
         HIP_TRY(hipStreamSynchronize(st));
-        const LoopFuse lf{ls->tab, (const LoopParams *)ls->params, ls->x, ls->step_ctr, ls->step_ctr + 1, cfg->sampler, cfg->clip_denoised, cfg->eta};
         bool fused = false;
         if (!ls->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&ls->cap_stream, hipStreamNonBlocking));
         hipStream_t cs = ls->cap_stream;
         HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         static const bool fuse_env = !(getenv("SURFD_LOOP_FUSE") && atoi(getenv("SURFD_LOOP_FUSE")) == 0);   // 0: separate step kernels (A/B timing)
-        rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, cs, ls->step_ctr, fuse_env ? &lf : nullptr, &fused);
+        rc = unet_forward_prepared(u, ls->x, 0, ls->x0, B, L, cs, ls->step_ctr, fuse_env ? lf_dev : nullptr, &fused);
         if (!rc && !fused) {
             hipLaunchKernelGGL(loop_step_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n, 256), 64)), dim3(256), 0, cs,
                                cfg->sampler, cfg->clip_denoised, cfg->eta, (const float *)ls->tab,

@@ -43,6 +43,8 @@ struct SegArgs {
     const float *gamma, *beta;
     int kg_off;            // first k-group of this segment in the packed K axis
     int cc;                // channels staged per chunk (multiple of 8; whole GN groups)
+    const float *add;      // Linear operands only: x[b][c] + add[step * add_step_stride + c] is what gets staged (nullable)
+    long add_step_stride;
 };
 
 struct ConvArgs {
@@ -234,6 +236,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs A) {
                         else
 #pragma unroll
                             for (int q = 0; q < 4; ++q) if (cg + q < S.C) v[i][q] = S.x[bs * S.bstride + cg + q];
+                        if (S.add) {          // the time part of the embedding joins the sample part here (one row per loop step)
+                            const float *ap = S.add + (A.step_ptr ? (long)(*A.step_ptr) * S.add_step_stride : 0L);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (cg + q < S.C) v[i][q] += ap[cg + q];
+                        }
                     }
                 }
                 prefetch_weights();
@@ -1167,7 +1174,8 @@ struct Resolved { float *ptr; long bstride; };
 // Launch one planned convolution.  `B` batch entries, operand length Lseg(ds) = ds ? L/ds : 1.
 int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext_in[2], const long ext_in_bs[2],
                 const int ext_bmod[2], float *ext_out, long ext_out_bs, const float *emb, long emb_bs, hipStream_t st,
-                const int *step_ptr = nullptr, const LoopFuse *lf = nullptr, bool *lf_done = nullptr) {
+                const int *step_ptr = nullptr, const LoopFuse *lf = nullptr, bool *lf_done = nullptr,
+                const float *lin_add = nullptr, long lin_add_step_stride = 0) {
     if (u->precision == 1 && c.f16_ok && (u->dbg_only < 0 || u->dbg_only == c.id)) {
         const ConvLaunchIO io{ext_in[0], ext_in_bs[0], ext_out, ext_out_bs, emb, emb_bs, step_ptr, lf, lf_done};
         const int r2 = launch_conv2(u, c, B, L, io, st);
@@ -1204,6 +1212,7 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
         S.bmod = (sp.src.buf < 0) ? ext_bmod[s] : 0;
         if (sp.gn) { S.gamma = u->vecs + u->vec_off[sp.gnkey + ".weight"]; S.beta = u->vecs + u->vec_off[sp.gnkey + ".bias"]; }
         S.kg_off = c.kg_off[s];
+        if (s == 0 && lin_add) { S.add = lin_add; S.add_step_stride = lin_add_step_stride; A.step_ptr = step_ptr; }
         const int lsl = sp.taps == 3 ? (sp.stride == 2 ? 2 * A.Lout + 1 : A.Lout + 2) : A.Lout;
         max_lsl = std::max(max_lsl, lsl);
     }
@@ -1287,6 +1296,7 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
     if (c.emb_off >= 0 && emb) {
         A.emb = emb + c.emb_off; A.step_ptr = step_ptr;
         A.emb_bstride = u->emb_shared ? 0 : emb_bs; A.emb_step_stride = u->emb_shared ? emb_bs : (long)B * emb_bs;
+        if (u->emb_ingraph) { A.step_ptr = nullptr; A.emb_step_stride = 0; }      // the iteration's own [B][14112] rows
     }
     if (c.res.buf != -1) { const Resolved r = resolve(c.res, c.ds_out, 0, false); A.res = r.ptr; A.res_bstride = r.bstride; }
     const Resolved o = resolve(c.dst, c.ds_out, 0, true);
@@ -1334,6 +1344,7 @@ int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, c
                                 int B, hipStream_t st, bool shared) {
     if (shared && (ctx || cls)) SURFD_FAIL(SURFD_ERR_ARG, "unet: shared embedding rows need an unconditional evaluation");
     if ((u->emb_shared != 0) != shared) { u->emb_shared = shared; u->ws_gen++; }       // captured graphs hold the strides
+    if (u->emb_ingraph) { u->emb_ingraph = 0; u->ws_gen++; }
     if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
     if ((u->cfg.num_classes > 0) != (cls != nullptr))
         SURFD_FAIL(SURFD_ERR_ARG, "unet: class labels must be given if and only if the model is class-conditional");
@@ -1386,6 +1397,79 @@ int unet_prepare_embeddings_dev(surfd_unet *u, const int64_t *t_dev, int rows, c
     return SURFD_OK;
 }
 
+static int ensure_t_dev(surfd_unet *u, int rows) {
+    if (rows > u->t_cap) {
+        if (u->t_dev) HIP_TRY(hipFree(u->t_dev));
+        u->t_dev = nullptr;
+        HIP_TRY(hipMalloc((void **)&u->t_dev, (size_t)rows * sizeof(int64_t)));
+        u->t_cap = rows;
+    }
+    return SURFD_OK;
+}
+
+int unet_prepare_loop_embeddings(surfd_unet *u, const int64_t *t_steps_host, int T, const float *ctx, const int64_t *cls, int B,
+                                 hipStream_t st) {
+    if (!ctx && !cls) SURFD_FAIL(SURFD_ERR_ARG, "unet: in-loop embedding rows are for conditioned loops (context and / or labels)");
+    if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
+    if ((u->cfg.num_classes > 0) != (cls != nullptr))
+        SURFD_FAIL(SURFD_ERR_ARG, "unet: class labels must be given if and only if the model is class-conditional");
+    if (ctx && u->cfg.context_dim <= 0) SURFD_FAIL(SURFD_ERR_ARG, "unet: model has no context embedding");
+    int rc = ensure_t_dev(u, T);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(u->t_dev, t_steps_host, (size_t)T * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the host vector may go away after we return
+    const int rows = std::max(T, B);      // temb / h1 / emb hold T rows, emb_table B rows of 14112
+    if (rows > u->emb_rows_cap) {
+        for (float **p : {&u->temb, &u->h1, &u->emb, &u->emb_table}) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
+        HIP_TRY(hipMalloc((void **)&u->temb, (size_t)rows * u->cfg.model_channels * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&u->h1, (size_t)rows * u->ted * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&u->emb, (size_t)rows * u->ted * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&u->emb_table, (size_t)rows * u->emb_total * sizeof(float)));
+        u->emb_rows_cap = rows;
+        u->ws_gen++;
+    }
+    if (B > u->emb_ctx_cap) {
+        if (u->emb_ctx) HIP_TRY(hipFree(u->emb_ctx));
+        u->emb_ctx = nullptr;
+        HIP_TRY(hipMalloc((void **)&u->emb_ctx, (size_t)B * u->ted * sizeof(float)));
+        u->emb_ctx_cap = B;
+        u->ws_gen++;
+    }
+    if (!u->emb_ingraph || u->emb_shared) { u->emb_ingraph = 1; u->emb_shared = 0; u->ws_gen++; }
+    const int mc = u->cfg.model_channels;
+    // ---- per step: time_embed(timestep_embedding(t_k)) -> u->emb[T][ted] --------------------------------------------
+    hipLaunchKernelGGL(temb_kernel, dim3((unsigned)std::min<long>(ceil_div<long>((long)T * mc / 2, 256), 1024)), dim3(256), 0, st, u->t_dev, T, mc, u->temb);
+    LAUNCH_CHECK();
+    {
+        const float *in[2] = {u->temb, nullptr}; const long bs[2] = {mc, 0}; const int bm[2] = {0, 0};
+        if ((rc = launch_conv(u, u->lin1, T, 1, in, bs, bm, u->h1, u->ted, nullptr, 0, st))) return rc;
+        ConvPlan l2 = u->lin2;           // time_embed.2 alone: first K segment, its own bias
+        l2.nseg = 1;
+        l2.bias_off = u->vec_off["time_embed.2.bias"];
+        const float *in2[2] = {u->h1, nullptr}; const long bs2[2] = {u->ted, 0};
+        if ((rc = launch_conv(u, l2, T, 1, in2, bs2, bm, u->emb, u->ted, nullptr, 0, st))) return rc;
+    }
+    // ---- per sample: sketch_emb(ctx) + label_emb[cls] -> emb_ctx[B][ted] ------------------------------------------------
+    if (ctx) {
+        ConvPlan l2 = u->lin2;           // sketch_emb alone: the second K segment of the same packed rows, its own bias
+        l2.nseg = 1;
+        l2.seg[0] = u->lin2.seg[1];
+        l2.kg_off[0] = u->lin2.kg_off[1];
+        l2.bias_off = u->vec_off["sketch_emb.bias"];
+        const float *in[2] = {ctx, nullptr}; const long bs[2] = {u->cfg.context_dim, 0}; const int bm[2] = {0, 0};
+        if ((rc = launch_conv(u, l2, B, 1, in, bs, bm, u->emb_ctx, u->ted, nullptr, 0, st))) return rc;
+    } else {
+        HIP_TRY(hipMemsetAsync(u->emb_ctx, 0, (size_t)B * u->ted * sizeof(float), st));
+    }
+    if (cls) {
+        hipLaunchKernelGGL(add_label_kernel, dim3((unsigned)std::min<long>(ceil_div<long>((long)B * u->ted, 256), 2048)), dim3(256), 0, st, u->emb_ctx, B,
+                           u->ted, (const float *)u->label_table, cls, B);
+        LAUNCH_CHECK();
+    }
+    u->emb_rows = B; u->emb_B = B;
+    return SURFD_OK;
+}
+
 int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows, const float *ctx, const int64_t *cls,
                             int B, hipStream_t st, bool shared) {
     if (rows > u->t_cap) {
@@ -1428,12 +1512,18 @@ int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, i
                           const int *step_ptr, const LoopFuse *lf, bool *lf_done) {
     if (!u->finalized) SURFD_FAIL(SURFD_ERR_STATE, "unet: parameters not finalized");
     if (row0 < 0 || row0 + (u->emb_shared ? 1 : B) > u->emb_rows) SURFD_FAIL(SURFD_ERR_STATE, "unet: embedding rows [%d,%d) not prepared", row0, row0 + B);
+    if (u->emb_ingraph && (row0 != 0 || B != u->emb_B)) SURFD_FAIL(SURFD_ERR_STATE, "unet: in-loop embedding rows were prepared for %d samples", u->emb_B);
     int max_ds = 1;
     for (auto &b : u->bufs) max_ds = std::max(max_ds, b.ds);
     if (L % max_ds || L < max_ds || L > 64 || (L & (L - 1))) SURFD_FAIL(SURFD_ERR_UNSUPPORTED, "unet: latent length %d must be a power of two in [%d, 64]", L, max_ds);
     int rc = ensure_workspace(u, B, L);
     if (rc) return rc;
     const float *emb = u->emb_table + (size_t)row0 * u->emb_total;
+    if (u->emb_ingraph) {
+        // emb_table[b] = emb_layers(SiLU(time_embed(t_k) + sample part[b])) for THIS iteration (openaimodel.py:724-735, 218-224)
+        const float *in[2] = {u->emb_ctx, nullptr}; const long bs[2] = {u->ted, 0}; const int bm[2] = {0, 0};
+        if ((rc = launch_conv(u, u->lin3, B, 1, in, bs, bm, u->emb_table, u->emb_total, nullptr, 0, st, step_ptr, nullptr, nullptr, u->emb, u->ted))) return rc;
+    }
     for (auto &op : u->ops)
         if ((rc = run_op(u, op, x, out, B, L, emb, st, step_ptr, lf, lf_done))) return rc;
     return SURFD_OK;

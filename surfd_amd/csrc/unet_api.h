@@ -27,10 +27,15 @@ struct LoopFuse {
 // shared: nothing but t enters the embedding (no context, no labels) -> one row per step, read by every sample.
 int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows, const float *ctx,
                             const int64_t *cls, int B, hipStream_t st, bool shared = false);
+// Conditioned reverse loops: what depends only on t (time_embed MLP, one row per STEP: t_steps_host[T]) and what depends only on
+// the sample (context / label embedding, one row per SAMPLE) are evaluated once; the 22 per-ResBlock rows of an iteration are
+// then produced inside the loop by one Linear launch (unet_forward_prepared with a step pointer).  Nothing is sized T x B.
+int unet_prepare_loop_embeddings(surfd_unet *u, const int64_t *t_steps_host, int T, const float *ctx, const int64_t *cls, int B,
+                                 hipStream_t st);
 // One denoiser evaluation using embedding rows [row0, row0 + B) of the prepared table (row row0 alone when the rows
 // are shared).  With step_ptr != nullptr the row block is (*step_ptr) * B (resp. row *step_ptr) instead (read on the
 // device: lets one captured hipGraph serve every iteration of the reverse loop).
-// lf != nullptr asks for the posterior update inside the head convolution; *lf_done says whether that happened (it does
+// lf (a DEVICE pointer) != nullptr asks for the posterior update inside the head convolution; *lf_done says whether that happened (it does
 // not when the head runs on the exact-fp32 kernel: the caller then launches the separate step kernels).
 int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, int B, int L, hipStream_t st,
                           const int *step_ptr = nullptr, const LoopFuse *lf = nullptr, bool *lf_done = nullptr);
@@ -58,7 +63,7 @@ struct LoopState {
     int *step_ctr = nullptr;        // device: current loop iteration k ([0]) and the head launch's arrival ticket ([1])
     float *x = nullptr, *x0 = nullptr;   // device: state and x0 prediction [B*L]
     size_t cap = 0;                 // floats allocated for x / x0
-    void *params = nullptr;         // device: LoopParams (caller pointers, refreshed per call)
+    void *params = nullptr;         // device: LoopParams (caller pointers, refreshed per call), followed by the LoopFuse record
     float *tab = nullptr;           // device: per-iteration coefficient rows [T][8]
     int tab_cap = 0;
     hipGraphExec_t exec = nullptr;  // cached instantiated step graph

@@ -71,6 +71,11 @@ struct surfd_unet {
     std::vector<float *> buf_ptr; int ws_B = 0, ws_L = 0;
     float *temb = nullptr, *h1 = nullptr, *emb = nullptr, *emb_table = nullptr; int emb_rows_cap = 0; int emb_rows = 0, emb_B = 0;
     int emb_shared = 0;                                // 1: one embedding row per loop step, shared by all samples (no context / labels)
+    // conditioned loops (context / labels): nothing scales with steps x samples.  time_embed(t) for every step [T][ted] (u->emb),
+    // the per-sample part sketch_emb(ctx) + label_emb[cls] [B][ted] (emb_ctx) once per loop, and INSIDE the captured graph one
+    // Linear launch per iteration: emb_table[B][14112] = emb_layers(SiLU(time part[k] + sample part[b]))
+    int emb_ingraph = 0;
+    float *emb_ctx = nullptr; int emb_ctx_cap = 0;
     int64_t *t_dev = nullptr; int t_cap = 0;
     float *part = nullptr; size_t part_floats = 0;     // split-K partial tiles
     long long *dbg = nullptr; int dbg_launch = 0;      // SURFD_CONV_DEBUG=1: per-launch phase stamps
@@ -101,7 +106,7 @@ struct ConvLaunchIO {
     float *ext_out; long ext_out_bs;         // external result  (View.buf == -3)
     const float *emb; long emb_bs;           // embedding rows of this evaluation (nullable)
     const int *step_ptr;                     // device loop counter (nullable)
-    const LoopFuse *lf = nullptr;            // posterior update in the epilogue of the head convolution (nullable)
+    const LoopFuse *lf = nullptr;            // DEVICE pointer: posterior update in the epilogue of the head convolution (nullable)
     bool *lf_done = nullptr;                 // set when the launch took it over
 };
 int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunchIO &io, hipStream_t st);

@@ -102,6 +102,21 @@ def test_decoder_ragged_vs_oracle(n):
     np.testing.assert_array_equal(udf_p.cpu().numpy(), udf_f.cpu().numpy()[perm.numpy()])
 
 
+def test_encoder_vs_golden_on_the_gpu(golden):
+    """a13: CoordsEncoder.encode (AutoEncoder/models/coordsenc.py:25-51) on the device against the reference's own output
+    (G7) — the product's dense encoder, and through it the columns the fused kernels rebuild per tile."""
+    from surfd_amd.cbndec import CoordsEncoder
+    g = golden("g7_encode")
+    enc = CoordsEncoder()
+    pts = torch.from_numpy(g["pts"]).cuda()
+    out = enc.encode_dense(pts)
+    assert out.is_cuda and tuple(out.shape) == tuple(g["enc"].shape)
+    np.testing.assert_allclose(out.cpu().numpy(), g["enc"], rtol=0, atol=2e-6)      # sin / cos of up to 2^9 * pi * x in fp32
+    lazy = enc.encode(pts)                                   # what the reference's call site gets: shape-compatible, dense on demand
+    assert tuple(lazy.shape) == tuple(g["enc"].shape)
+    np.testing.assert_array_equal(lazy.materialize().cpu().numpy(), out.cpu().numpy())
+
+
 def test_decoder_saturation_edge_cases():
     """logit >~ 17 -> udf == 0.0 exactly and a zero gradient vector."""
     dec, sd = _decoder(32)
@@ -427,13 +442,15 @@ def test_decoder_f16x2_vs_fp32_kernel(golden):
     assert torch.isfinite(dec._logits_xyz(far, 0)).all()
 
 
-def test_grid_512_properties_D64():
-    """Configs C4 / C5 at their real grid size: 512^3 coarse-to-fine fill with the D=64 decoder — level counts,
-    gradient support, unit norms, idempotence and direct re-evaluation of sampled voxels."""
+@pytest.mark.parametrize("D", [32, 64])
+def test_grid_512_properties(D):
+    """The configurations at their real grid size: 512^3 coarse-to-fine fill with the native decoder — D=32 is C3 (the
+    metric's grid), D=64 is C4 / C5 — level counts, gradient support, unit norms, idempotence and direct re-evaluation of
+    sampled voxels."""
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
-    dec, sd = _decoder(64)
-    lat = (torch.randn(1, 64, generator=torch.Generator().manual_seed(19)) * 0.8).cuda()
+    dec, sd = _decoder(D)
+    lat = (torch.randn(1, D, generator=torch.Generator().manual_seed(19)) * 0.8).cuda()
     gf = GridFiller(512)
     udf, grads = gf.fill_grid(make_udf_func(dec, lat), 2 ** 16)
     st = gf.last_stats
