@@ -101,6 +101,11 @@ def parse():
     ap.add_argument("--mesh-threads", type=int, default=0, help="e2: host meshing threads per rank (0 = min(8, cores / ranks - chains))")
     ap.add_argument("--mode", choices=["shape-parallel", "grid-shard"], default="shape-parallel",
                     help="grid-shard: every level of one shape's grid split over the ranks (needs --gpus >= 2 to mean anything)")
+    ap.add_argument("--shard-path", choices=["native", "callback"], default="native",
+                    help="grid-shard: native = surfd_grid_shard_* (voxel-ordered lists, tiles r, r + G, ... of every level, fixed-capacity buffers summed "
+                         "over the ranks, no host read between levels); callback = round 3's ShardedField over the host-callback grid API")
+    ap.add_argument("--shard-capacity", type=int, default=1 << 24, help="grid-shard native: points a level's exchange buffer holds")
+    ap.add_argument("--shard-grad-capacity", type=int, default=1 << 21, help="grid-shard native: gradient points the exchange buffer holds")
     ap.add_argument("--batch-grids", type=int, default=1,
                     help="1: the grids of a step are refined together, one decoder launch per level for all shapes "
                          "(meshudf.fill_grids); 0: shape after shape")
@@ -795,11 +800,12 @@ def main():
 def grid_shard_main(a, world, rank):
     """--mode grid-shard (north star: "shard the per-sample 512^3 grid evaluation across the GPUs"): the reverse loop of a
     step's B shapes is replicated (deterministic: every rank computes the same latents), then every refinement level of
-    every shape's grid is split over the ranks by index range of the level's point list (voxel order, the same on every
-    rank) — each rank runs the decoder kernel on its slice, ncclAllGather over xGMI returns the whole level to everybody
-    (surfd_amd.parallel.ShardedField over GridFiller's callback path: 4 B per point per level, 12 B per gradient point).
-    Strong scaling of one shape's latency; one host read of the level's length per level (the list lengths live on the
-    device) is the only synchronisation besides the collective."""
+    every shape's grid is split over the ranks.  Native path (default, GridFiller.fill_grid_sharded over surfd_grid_shard_*):
+    the level's point list is voxel-ordered on every rank (ordered compaction on the device), rank r runs the decoder on the
+    64-point tiles r, r + G, ... into a fixed-capacity value buffer, the buffers are summed over the ranks (ncclAllReduce
+    over xGMI; every entry is non-zero on one rank), every rank commits the whole level — no host read anywhere between the
+    latent and the finished grid.  Callback path (--shard-path callback, round 3): surfd_amd.parallel.ShardedField over
+    GridFiller's callback API, one host read of the level's length per level.  Strong scaling of one shape's latency."""
     from surfd_amd import synth
     from surfd_amd.cbndec import make_udf_func
     from surfd_amd.meshudf import GridFiller
@@ -823,12 +829,18 @@ def grid_shard_main(a, world, rank):
         lat = diffusion.p_sample_loop(model, (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise_bank[s], fused=True)
         dec.bind_latents(lat.reshape(B, a.latent))
         for k in range(B):
-            filler.fill_grid(ShardedField(make_udf_func(dec, lat[k], sample=k)), 2 ** 22, out=(udf, grads), stats=True)
-            fwd_pts[0] += sum(filler.last_stats["fwd_per_level"])
+            if a.shard_path == "native":
+                filler.fill_grid_sharded(make_udf_func(dec, lat[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=False,
+                                         capacity=a.shard_capacity, grad_capacity=a.shard_grad_capacity)
+            else:
+                filler.fill_grid(ShardedField(make_udf_func(dec, lat[k], sample=k)), 2 ** 22, out=(udf, grads), stats=True)
+                fwd_pts[0] += sum(filler.last_stats["fwd_per_level"])
         return lat
 
     for s in range(a.warmup):
         one_step(s)
+    if filler._handle is not None:
+        filler.totals(reset=True)
     fwd_pts[0] = 0.0
     barrier(world)
     t0 = time.perf_counter()
@@ -836,6 +848,36 @@ def grid_shard_main(a, world, rank):
         lat = one_step(s)
     torch.cuda.synchronize()
     local_ms = (time.perf_counter() - t0) * 1e3
+    if a.shard_path == "native":
+        tot = filler.totals(reset=True)             # running totals kept on the device by the fills: one read, after the clock
+        fwd_pts[0] = float(sum(tot["fwd_per_level"]))
+        # capacity check, once, on the last shape's counts (a cut level would have changed the totals of every shape alike)
+        st_last = filler._stats()
+        caps = [min(a.shard_capacity, 32 ** 3 if l == 0 else 7 * filler.N_levels[l - 1] ** 3) for l in range(len(filler.N_levels))]
+        assert all(c <= cap for c, cap in zip(st_last["fwd_per_level"], caps)) and st_last["grad"] <= min(a.shard_grad_capacity, N ** 3), \
+            f"--shard-capacity {a.shard_capacity} / --shard-grad-capacity {a.shard_grad_capacity} is too small for this field: {st_last}"
+    # the same shapes through the fused single-rank fill, timed the same way: what the sharded path costs by construction
+    fused_ms = None
+    if rank == 0 or world > 1:
+        ff = GridFiller(N)
+        ff.fill_grid(make_udf_func(dec, lat[0], sample=0), 2 ** 16, out=(udf, grads), stats=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(B):
+            ff.fill_grid(make_udf_func(dec, lat[k], sample=k), 2 ** 16, out=(udf, grads), stats=False)
+        torch.cuda.synchronize()
+        fused_ms = (time.perf_counter() - t1) * 1e3 / B
+    shard_ms = None
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for k in range(B):
+        if a.shard_path == "native":
+            filler.fill_grid_sharded(make_udf_func(dec, lat[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=False, capacity=a.shard_capacity,
+                                     grad_capacity=a.shard_grad_capacity)
+        else:
+            filler.fill_grid(ShardedField(make_udf_func(dec, lat[k], sample=k)), 2 ** 22, out=(udf, grads), stats=False)
+    torch.cuda.synchronize()
+    shard_ms = (time.perf_counter() - t1) * 1e3 / B
     barrier(world)
     elapsed = time.perf_counter() - t0
     per_rank = None
@@ -858,8 +900,15 @@ def grid_shard_main(a, world, rank):
            "config": {"workload": f"{cfg['name']}; grid-shard mode: reverse loop replicated, every level of every shape's {N}^3 grid split over {world} rank(s) "
                                   "by index range, values returned by ncclAllGather (end point E1)", "mode": "grid-shard", "baseline_config": a.config,
                       "shapes_per_step": B, "resolution": N, "diffusion_steps": T, "decoder_fwd_queries_per_shape": fwd_pts[0] / max(shapes, 1),
-                      "host_syncs_per_shape": len(filler.N_levels) + 1,
-                      "parallelism": f"grid-shard x{world}: all_gather of 4 B per point per level + 12 B per gradient point over xGMI"}}
+                      "shard_path": a.shard_path, "host_syncs_per_shape": 0 if a.shard_path == "native" else len(filler.N_levels) + 1,
+                      "exchange_capacity_points": {"per_level": a.shard_capacity, "gradients": a.shard_grad_capacity} if a.shard_path == "native" else None,
+                      "parallelism": (f"grid-shard x{world}: rank r evaluates tiles r, r + {world}, ... of every level's voxel-ordered list; fixed-capacity value "
+                                      "buffers summed over the ranks (ncclAllReduce over xGMI), 4 B per point per level + 12 B per gradient point")
+                                     if a.shard_path == "native" else
+                                     f"grid-shard x{world}: all_gather of 4 B per point per level + 12 B per gradient point over xGMI"},
+           "grid_ms_per_shape": {"sharded": shard_ms, "fused_single_rank_fill": fused_ms,
+                                 "sharded_over_fused": (shard_ms / fused_ms) if fused_ms else None,
+                                 "note": "the shapes of the last step again, grids only, after the timed region"}}
     if per_rank is not None:
         out["per_rank"] = per_rank
     print(json.dumps(out))

@@ -253,6 +253,22 @@ int surfd_grid_level_commit(surfd_grid *g, int level, const float *values, int64
 int surfd_grid_grad_points(surfd_grid *g, float *xyz, int64_t capacity, int64_t *n, surfd_stream s);
 int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_stream s);
 
+/* Grid-shard mode (no reference counterpart: the reference fills one grid on one device, meshudf/meshudf.py:123-206; this is the
+ * north star's "shard the per-sample 512^3 grid evaluation across the GPUs").  Every one of `world` ranks runs, on its own device,
+ *   shard_begin -> per level { shard_level_eval -> [sum the `vals` buffers of the ranks, e.g. ncclAllReduce] -> shard_level_commit }
+ *               -> shard_grad_eval -> [sum `ngrads`] -> shard_grad_commit
+ * with the native decoder: rank r evaluates the 64-point tiles r, r + world, ... of each level's VOXEL-ORDERED point list (the
+ * same list on every rank) into vals[point number] and leaves the other entries untouched (zero them first).  All calls are
+ * stream-ordered and none reads a count back: list lengths stay on the device, `capacity` (points) bounds what a level may hold —
+ * compare surfd_grid_get_stats with it afterwards.  With world = 1 the result equals surfd_grid_fill bit for bit. */
+int surfd_grid_shard_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s);
+int surfd_grid_shard_level_eval(surfd_grid *g, surfd_decoder *d, int sample, int level, int rank, int world, float *vals,
+                                int64_t capacity, surfd_stream s);
+int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, int64_t capacity, surfd_stream s);
+int surfd_grid_shard_grad_eval(surfd_grid *g, surfd_decoder *d, int sample, int rank, int world, float *ngrads, int64_t capacity,
+                               surfd_stream s);
+int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, surfd_stream s);
+
 /* ------------------------------------------------------------------------------------ */
 /* UDF marching cubes (host side, no device): udf_mc_lewiner / marching_cubes_udf        */
 /* (meshudf/_marching_cubes_lewiner.py:87-154, meshudf/_marching_cubes_lewiner_cy.pyx:1115-1775) */

@@ -633,7 +633,8 @@ __global__ __launch_bounds__(256, 1) void decoder_kernel(DecParams P, PtBatch B)
     const long npts = pt_count(io);
     const long ntiles = (npts + TP - 1) / TP;
     const float *tab_sample = P.tab + (size_t)B.sample[bi] * NCBN * 2 * H;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long tstep = io.shard_n > 1 ? io.shard_n : 1;       // grid-shard mode: this rank's tiles are shard_i, shard_i + shard_n, ...
+    for (long tile = blockIdx.x * tstep + (io.shard_n > 1 ? io.shard_i : 0); tile < ntiles; tile += gridDim.x * tstep) {
         const long e0 = tile * TP;
         // re-materialise the arena bases per tile: keeps the compiler from hoisting ~100 derived
         // 64-bit layer addresses out of the tile loop and spilling them to scratch
@@ -1327,7 +1328,8 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     const long npts = pt_count(io);
     const long ntiles = (npts + TP - 1) / TP;
     const float *tab_sample = P.tab + (size_t)B.sample[bi] * NCBN * 2 * H;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long tstep = io.shard_n > 1 ? io.shard_n : 1;       // grid-shard mode: this rank's tiles are shard_i, shard_i + shard_n, ...
+    for (long tile = blockIdx.x * tstep + (io.shard_n > 1 ? io.shard_i : 0); tile < ntiles; tile += gridDim.x * tstep) {
         const long e0 = tile * TP;
         const float *vecs_ = P.vecs, *tab_ = tab_sample;
         const _Float16 *whf = P.whf;

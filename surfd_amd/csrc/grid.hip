@@ -180,8 +180,9 @@ __global__ __launch_bounds__(1024) void select_scan_kernel(int *wave_counts, int
     for (int i = 0; i < per; ++i) { const int k = t * per + i; if (k < m) { const int c = wave_counts[k]; wave_counts[k] = run; run += c; } }
     if (t == 1023) *count = part[1023];
 }
-template <class Pred>
-__global__ __launch_bounds__(256) void select_write_kernel(Pred pred, long n, const int *wave_offsets, int *out) {
+struct Identity { __device__ __forceinline__ int operator()(int i) const { return i; } };
+template <class Pred, class Xf = Identity>
+__global__ __launch_bounds__(256) void select_write_kernel(Pred pred, long n, const int *wave_offsets, int *out, Xf xf = Xf()) {
     const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const long lo = w * SEL_SPAN, hi = min(n, lo + SEL_SPAN);
@@ -191,8 +192,59 @@ __global__ __launch_bounds__(256) void select_write_kernel(Pred pred, long n, co
         const long e = e0 + lane;
         const bool p = e < hi && pred((int)e);
         const unsigned long long m = __ballot(p);
-        if (p) out[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)e;
+        if (p) out[off + __popcll(m & ((1ull << lane) - 1ull))] = xf((int)e);
         off += __popcll(m);
+    }
+}
+
+// ---- grid-shard mode: the same classification with a VOXEL-ORDERED result --------------------------------------------
+// Several ranks evaluate one shape's grid: rank r takes the 64-point tiles r, r + G, ... of every level's point list, so the
+// list must be the same on every rank — and classify_kernel's appends are in scheduling order.  Here a level is classified
+// over its whole lattice (n_l^3 <= 256^3 points: 1 byte of the parent level's flags + 4 bytes of udf each): flag_l[li] = the
+// lattice point is active (level 0: all; else its parent block was close) and close; the next level's parents are then the
+// ORDERED compaction of the flags (count on the device, no sort), the far blocks are appended in any order (the fill does not
+// care).  Same sets as classify_kernel, hence the same grid as the fused fill, bit for bit.
+struct LatticeGeom { int n, log2n, N, s; };      // lattice width (power of two), grid width, stride
+__device__ __forceinline__ int lattice_voxel(const LatticeGeom &G, int li) {
+    const int K = li & (G.n - 1), J = (li >> G.log2n) & (G.n - 1), I = li >> (2 * G.log2n);
+    return ((I * G.N + J) * G.N + K) * G.s;
+}
+__global__ __launch_bounds__(256) void classify_flag_kernel(LatticeGeom G, const unsigned char *parent_flag, const float *udf, float thr,
+                                                            unsigned char *flag, int *far_list, int *far_count) {
+    const long n3 = 1L << (3 * G.log2n);
+    for (long e0 = blockIdx.x * (long)blockDim.x; e0 < n3; e0 += (long)gridDim.x * blockDim.x) {
+        const long e = e0 + threadIdx.x;
+        bool far = false;
+        int vox = 0;
+        if (e < n3) {
+            const int li = (int)e;
+            bool active = true;
+            if (parent_flag) {
+                const int K = li & (G.n - 1), J = (li >> G.log2n) & (G.n - 1), I = li >> (2 * G.log2n);
+                active = parent_flag[((((I >> 1) << (G.log2n - 1)) + (J >> 1)) << (G.log2n - 1)) + (K >> 1)] != 0;
+            }
+            vox = lattice_voxel(G, li);
+            const bool close = active && fabsf(udf[vox]) < thr;
+            flag[li] = close ? 1 : 0;
+            far = active && !close;
+        }
+        const int slot = wave_append_slot(far_count, far);
+        if (slot >= 0) far_list[slot] = vox;
+    }
+}
+struct FlagSet {
+    const unsigned char *flag;
+    __device__ __forceinline__ bool operator()(const int &i) const { return flag[i] != 0; }
+};
+struct LatticeToVoxel {
+    LatticeGeom G;
+    __device__ __forceinline__ int operator()(int li) const { return lattice_voxel(G, li); }
+};
+__global__ void grad_commit_dev_kernel(const int *list, const int *count, long cap, const float *ng, float *grads) {
+    const long n = min((long)*count, cap);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long idx = list[e];
+        grads[idx * 3 + 0] = ng[e * 3 + 0]; grads[idx * 3 + 1] = ng[e * 3 + 1]; grads[idx * 3 + 2] = ng[e * 3 + 2];
     }
 }
 
@@ -223,6 +275,7 @@ struct surfd_grid {
     int *sort_out = nullptr; long sort_cap = 0; void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;   // callback path: deterministic list order (allocated on first use)
     unsigned long long *totals = nullptr;            // [MAX_LEVELS] forward queries per level, [MAX_LEVELS] gradient queries, [MAX_LEVELS + 1] fills — since the last reset
     void *sel_tmp = nullptr; size_t sel_tmp_bytes = 0;                                // fused path: ordered compaction of the gradient voxels
+    unsigned char *flags[SURFD_GRID_MAX_LEVELS] = {};                                 // grid-shard mode: close flags per level lattice (allocated on first use)
 };
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -263,15 +316,15 @@ struct BelowThreshold {
     __device__ __forceinline__ bool operator()(const int &i) const { return udf[i] < thr; }
 };
 
-template <class Pred>
-static int ordered_select(Pred pred, long n, int *wave_tmp, int *out, int *count, hipStream_t st) {
+template <class Pred, class Xf = Identity>
+static int ordered_select(Pred pred, long n, int *wave_tmp, int *out, int *count, hipStream_t st, Xf xf = Xf()) {
     const int m = (int)ceil_div<long>(n, SEL_SPAN);
     const unsigned blocks = (unsigned)ceil_div(m, 4);
     hipLaunchKernelGGL((select_count_kernel<Pred>), dim3(blocks), dim3(256), 0, st, pred, n, wave_tmp);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, st, wave_tmp, m, count);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL((select_write_kernel<Pred>), dim3(blocks), dim3(256), 0, st, pred, n, (const int *)wave_tmp, out);
+    hipLaunchKernelGGL((select_write_kernel<Pred, Xf>), dim3(blocks), dim3(256), 0, st, pred, n, (const int *)wave_tmp, out, xf);
     LAUNCH_CHECK();
     return SURFD_OK;
 }
@@ -381,6 +434,8 @@ void surfd_grid_destroy(surfd_grid *g) {
     if (g->sort_out) (void)hipFree(g->sort_out);
     if (g->sort_tmp) (void)hipFree(g->sort_tmp);
     if (g->sel_tmp) (void)hipFree(g->sel_tmp);
+    for (int l = 0; l < SURFD_GRID_MAX_LEVELS; ++l)
+        if (g->flags[l]) (void)hipFree(g->flags[l]);
     delete g;
 }
 
@@ -710,6 +765,92 @@ int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_
                        as_stream(s), (const int *)g->grad_list, (long)n, ngrads, g->cur_grads);
     LAUNCH_CHECK();
     return SURFD_OK;
+}
+
+
+// ---- grid-shard mode, native (north star: "shard the per-sample 512^3 grid evaluation across the GPUs") ---------
+// One shape, `world` ranks, every rank runs the same calls on its own device:
+//   begin -> per level { level_eval (this rank's tiles -> vals[e]) -> [sum-reduce / gather vals over the ranks] -> level_commit }
+//         -> grad_eval (this rank's tiles of the voxel-ordered gradient list -> ngrads[e][3]) -> [reduce] -> grad_commit
+// Everything is stream-ordered; no call reads a count back: the lists are voxel-ordered on every rank (classify_flag_kernel +
+// ordered compaction), their lengths stay in device counters, the exchange buffers have a caller-chosen fixed capacity (a level
+// longer than that is cut — surfd_grid_get_stats shows the true counts afterwards, compare them with the capacity).
+static int refine_level_ordered(surfd_grid *g, int level, float *udf, hipStream_t st) {
+    if (g->levels[level] >= g->N) return SURFD_OK;
+    const int n = g->levels[level];
+    const long n3 = (long)n * n * n;
+    if (!g->flags[level]) HIP_TRY(hipMalloc((void **)&g->flags[level], (size_t)n3));
+    LatticeGeom G{n, ilog2(n), g->N, g->N / n};
+    hipLaunchKernelGGL(classify_flag_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n3, 256), 4096)), dim3(256), 0, st, G,
+                       (const unsigned char *)(level > 0 ? g->flags[level - 1] : nullptr), (const float *)udf, g->refine[level],
+                       g->flags[level], g->far_list, g->counters + CTR_FAR + level);
+    LAUNCH_CHECK();
+    int rc = ordered_select(FlagSet{g->flags[level]}, n3, (int *)g->sel_tmp, g->parents[level + 1], g->counters + CTR_PARENT + level + 1, st,
+                            LatticeToVoxel{G});
+    if (rc) return rc;
+    const int s = g->N / n;
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, (const int *)g->far_list, (const int *)(g->counters + CTR_FAR + level), s,
+                       ilog2(s), g->N, udf, g->grad_thr, (int *)nullptr, g->counters + CTR_GRAD);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+int surfd_grid_shard_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s) {
+    return surfd_grid_begin(g, udf, grads, s);
+}
+
+int surfd_grid_shard_level_eval(surfd_grid *g, surfd_decoder *d, int sample, int level, int rank, int world, float *vals,
+                                int64_t capacity, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_shard_level_eval");
+    if (rc) return rc;
+    if (!g->cur_udf) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_level_eval: call surfd_grid_shard_begin first");
+    if (level < 0 || level >= g->n_levels || !vals || capacity < 1 || world < 1 || rank < 0 || rank >= world)
+        SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_eval: bad argument (level %d, rank %d of %d)", level, rank, world);
+    PtIO io = eval_io(g, level);
+    io.out_udf = vals; io.cap = capacity; io.shard_n = world; io.shard_i = rank;
+    const long hint = level == 0 ? ceil_div<long>(ceil_div<long>(std::min<long>(io.n, capacity), 64), world) : -1;
+    return decoder_launch(d, sample, io, false, hint, as_stream(s));
+}
+
+int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, int64_t capacity, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_shard_level_commit");
+    if (rc) return rc;
+    if (!g->cur_udf) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_level_commit: call surfd_grid_shard_begin first");
+    if (level < 0 || level >= g->n_levels || !vals || capacity < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_commit: bad argument");
+    hipStream_t st = as_stream(s);
+    PtIO io = eval_io(g, level);
+    io.grid_udf = g->cur_udf; io.cap = capacity;
+    const long upper = level == 0 ? io.n : capacity;
+    hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(upper, 256), 4096)), dim3(256), 0, st, io, vals);
+    LAUNCH_CHECK();
+    return refine_level_ordered(g, level, g->cur_udf, st);
+}
+
+int surfd_grid_shard_grad_eval(surfd_grid *g, surfd_decoder *d, int sample, int rank, int world, float *ngrads, int64_t capacity,
+                               surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_shard_grad_eval");
+    if (rc) return rc;
+    if (!g->cur_udf || !g->cur_grads) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_grad_eval: surfd_grid_shard_begin was not given a gradient buffer");
+    if (!ngrads || capacity < 1 || world < 1 || rank < 0 || rank >= world) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_grad_eval: bad argument");
+    hipStream_t st = as_stream(s);
+    if ((rc = compact_grad_list(g, g->cur_udf, g->grad_thr, st))) return rc;          // voxel order: the same list on every rank
+    PtIO io = base_io(g);
+    io.mode = PT_LIST; io.list = g->grad_list; io.count_dev = g->counters + CTR_GRAD;
+    io.out_ngrad = ngrads; io.cap = capacity; io.shard_n = world; io.shard_i = rank;
+    return decoder_launch(d, sample, io, true, -1, st);
+}
+
+int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_shard_grad_commit");
+    if (rc) return rc;
+    if (!g->cur_grads) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_grad_commit: no gradient buffer was given to surfd_grid_shard_begin");
+    if (!ngrads || capacity < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_grad_commit: bad argument");
+    hipStream_t st = as_stream(s);
+    hipLaunchKernelGGL(grad_commit_dev_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(capacity, 256), 4096)), dim3(256), 0, st,
+                       (const int *)g->grad_list, (const int *)(g->counters + CTR_GRAD), (long)capacity, ngrads, g->cur_grads);
+    LAUNCH_CHECK();
+    g->dense_last = false;
+    return add_to_totals(g, 0, st);
 }
 
 }  // extern "C"

@@ -37,12 +37,20 @@ struct PtIO {
     int *grad_list;                           // voxels with udf < grad_thr are appended here
     int *grad_count;
     float grad_thr;
+    // grid-shard mode (one shape evaluated by several ranks): this launch walks only the 64-point tiles t = shard_i (mod shard_n)
+    // of the source (shard_n <= 1: all of them); cap > 0 bounds the point count (the exchange buffers of the ranks have a fixed
+    // capacity: the count itself lives on the device)
+    int shard_n, shard_i;
+    long cap;
 };
 
 __device__ __forceinline__ long pt_count(const PtIO &io) {
-    if (io.count_dev == nullptr) return io.n;
-    const long c = *io.count_dev;
-    return io.mode == PT_CHILDREN ? 7 * c : (io.mode == PT_CHILDREN8 ? 8 * c : c);
+    long n = io.n;
+    if (io.count_dev != nullptr) {
+        const long c = *io.count_dev;
+        n = io.mode == PT_CHILDREN ? 7 * c : (io.mode == PT_CHILDREN8 ? 8 * c : c);
+    }
+    return io.cap > 0 ? min(n, io.cap) : n;
 }
 
 // voxel index of point e (grid modes only).  Point numbers fit 32 bits (at most 8 children of at most N^3 / 8 cells, N <= 1024):

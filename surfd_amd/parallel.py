@@ -62,6 +62,21 @@ def gather_latents(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
     return res.to(local.device) if via_host else res
 
 
+def sum_over_ranks(buf: torch.Tensor) -> None:
+    """In-place sum of a buffer over the ranks (grid-shard mode: every entry is non-zero on exactly one rank, so the sum IS the
+    exchange — x + 0 is exact).  ncclAllReduce over xGMI with backend "nccl"; gloo moves host memory, device tensors take a round
+    trip through the host there (CPU tests; ranks sharing one GPU)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    if buf.is_cuda and dist.get_backend() == "gloo":
+        h = buf.cpu()
+        dist.all_reduce(h)
+        buf.copy_(h)
+    else:
+        dist.all_reduce(buf)
+
+
 def sample_sharded(diffusion, model, total: int, latent_len: int, sampler: str = "ddpm", seed: int = 1234,
                    model_kwargs_fn=None, gather: bool = True, **loop_kwargs):
     """Runs the reverse loop for this rank's block of `total` shapes and (optionally) gathers all

@@ -687,3 +687,80 @@ def test_sharded_field_two_gpus_native_decoder():
     mp.spawn(_two_gpu_shard_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0][0] and out[0][1] and out[1][0] and out[1][1]
     assert torch.equal(out[0][2], out[1][2]) and out[0][3] == out[1][3] > 0
+
+
+# ---- grid-shard mode, native (surfd_grid_shard_*: no host read between levels, voxel-ordered lists, tiles r, r + G, ...) ----
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
+def test_native_sharded_fill_equals_fused_fill(world, precision):
+    """§8e: the native sharded fill with `world` ranks — played in turn by this process (simulate_ranks), so the tile split, the
+    fixed-capacity buffers, the ordered classification and the device-side counts are all exercised on one GPU — gives the grid
+    AND the gradients of the fused single-rank fill, bit for bit (same voxel-ordered gradient list, same 64-point tiles)."""
+    from surfd_amd.cbndec import make_udf_func
+    from surfd_amd.meshudf import GridFiller
+    dec, _ = _decoder(32)
+    dec.set_precision(precision)
+    try:
+        lat = (torch.randn(1, 32, generator=torch.Generator().manual_seed(23)) * 0.8).cuda()
+        f = make_udf_func(dec, lat)
+        ref = GridFiller(128)
+        udf_1, grads_1 = ref.fill_grid(f, 2 ** 16)
+        gf = GridFiller(128)
+        udf_s, grads_s = gf.fill_grid_sharded(f, world=world, simulate_ranks=True, capacity=1 << 21)
+        assert gf.last_stats == ref.last_stats and gf.last_stats["grad"] > 0
+        assert torch.equal(udf_1, udf_s) and torch.equal(grads_1, grads_s)
+        # a second shape on the same handle (buffers, flags and counters are reused)
+        lat2 = (torch.randn(1, 32, generator=torch.Generator().manual_seed(24)) * 0.8).cuda()
+        f2 = make_udf_func(dec, lat2)
+        a, b = ref.fill_grid(f2, 2 ** 16)
+        c, d = gf.fill_grid_sharded(f2, world=world, simulate_ranks=True, capacity=1 << 21)
+        assert torch.equal(a, c) and torch.equal(b, d)
+        # a level longer than the exchange buffers is reported, not silently cut
+        with pytest.raises(RuntimeError, match="capacity"):
+            GridFiller(128).fill_grid_sharded(f, world=world, simulate_ranks=True, capacity=4096)
+        with pytest.raises(RuntimeError, match="capacity"):
+            GridFiller(128).fill_grid_sharded(f, world=world, simulate_ranks=True, grad_capacity=64)
+    finally:
+        dec.set_precision("f16x2")
+
+
+def _native_shard_worker(rank, world, port, out, backend):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)          # nccl = RCCL over xGMI; gloo: the ranks share GPU 0
+    try:
+        from surfd_amd.cbndec import make_udf_func
+        from surfd_amd.meshudf import GridFiller
+        dec, _ = _decoder(32)
+        lat = (torch.randn(1, 32, generator=torch.Generator().manual_seed(22)) * 0.8).cuda()
+        f = make_udf_func(dec, lat)
+        udf_1, grads_1 = GridFiller(64).fill_grid(f, 2 ** 16)                                        # this rank alone, fused fill
+        udf_s, grads_s = GridFiller(64).fill_grid_sharded(f, rank=rank, world=world, capacity=1 << 20)   # tiles rank, rank + world, ...
+        out[rank] = (torch.equal(udf_1, udf_s), torch.equal(grads_1, grads_s), udf_s.cpu(), int((udf_s < 0.05).sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_native_shard(backend):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_native_shard_worker, args=(2, port, out, backend), nprocs=2, join=True)
+    assert out[0][0] and out[0][1] and out[1][0] and out[1][1]
+    assert torch.equal(out[0][2], out[1][2]) and out[0][3] == out[1][3] > 0
+
+
+def test_native_sharded_fill_two_ranks_over_gloo_on_one_gpu():
+    """Two PROCESSES, one GPU, gloo: each rank evaluates every second tile, the value buffers are summed over the ranks
+    (through the host with this backend), both end with the fused fill's grid and gradients bit for bit."""
+    _run_native_shard("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="grid-shard over RCCL needs two GPUs (1-GPU boxes skip; the gloo variant above covers the logic)")
+def test_native_sharded_fill_two_gpus_over_rccl():
+    _run_native_shard("nccl")
