@@ -82,7 +82,7 @@ def parse():
                          "default 2 (phased) / 3 (overlap)")
     ap.add_argument("--loop-batches", type=int, default=10,
                     help="phased: steps whose latents ride in ONE wide reverse loop (10 x 8 = 80 latents per loop)")
-    ap.add_argument("--wide-design-batch", type=int, default=32,
+    ap.add_argument("--wide-design-batch", type=int, default=80,
                     help="phased: design batch of the conv kernel's wide form (MDM.set_wide); the K split, hence the bits, depend on it, not on the loop width")
     ap.add_argument("--overlap-blocks", type=int, default=0,
                     help="phased: 0 = time-sliced rounds; D > 0 = the loops of round r + 1 run next to the grids of round r, which then "

@@ -877,7 +877,9 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     // K slices over workgroups when (tiles x batch chunks) under-fills the chip: whole K blocks per slice
     const int nch = c.nblk[0] + (c.nseg > 1 ? c.nblk[1] : 0);
     static const int ks_fill_env = env_int("SURFD_CONV2_FILL", 0);
-    const int ks_fill = ks_fill_env ? ks_fill_env : 2 * u->cu_budget;  // workgroups aimed at: two per CU (measured: 1.555 -> 1.472 ms per evaluation)
+    // workgroups aimed at: as many as fit the chip at once — two per CU (measured: 1.555 -> 1.472 ms per evaluation), three in the
+    // lean form (80 latents, design batch 80: 2.49 -> 2.43 ms per evaluation alone, 2 x 80: 21.6 -> 20.6 us per evaluation and latent)
+    const int ks_fill = ks_fill_env ? ks_fill_env : (lean ? SURFD_C2_LEAN_WAVES : 2) * u->cu_budget;
     static const int ks_max = env_int("SURFD_CONV2_KSMAX", 16);
     static const int ks_min_base = env_int("SURFD_CONV2_NOSPLIT_ABOVE", 200);
     const int base = A.ntiles * A.nby;

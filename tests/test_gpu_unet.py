@@ -469,9 +469,10 @@ def test_per_module_activations_vs_golden(golden):
 
 # ---- wide form of the conv kernel (MDM.set_wide): four row tiles per workgroup, batch-independent K split ----
 @pytest.fixture
-def wide_model():
+def wide_model(request):
+    """design batch 32 unless a test asks for another one (indirect parameter): 80 is what bench.py rides"""
     model, diff, sd = _model("no_cond")
-    model.set_wide(32)
+    model.set_wide(getattr(request, "param", 32))
     try:
         yield model, diff, sd
     finally:
@@ -494,6 +495,7 @@ def test_wide_form_forward_vs_oracle(wide_model, B, L):
     assert model.saturation_count() == 0
 
 
+@pytest.mark.parametrize("wide_model", [32, 80], indirect=True)
 def test_wide_form_vs_golden_modules_and_chain(wide_model, golden):
     """The wide form against the same reference-made fixtures as the latency form: whole forward (G3), per-module
     activations (G4) and the 1000-step contractive chain end to end (G12)."""
