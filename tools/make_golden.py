@@ -270,6 +270,38 @@ def g7_g8(R):
         save(f"g8_decoder_D{D}", lat=lat, pts=pts, logit=logit, udf=udf, ngrad=grads)
 
 
+def g8_direction_flips(R):
+    """The number behind the gradient-direction tolerance (tests/test_gpu_decoder_grid.py:_check_directions): how far the
+    REFERENCE's own fp32 sample_grads is from an fp64 evaluation of the same decoder on the G8 points.  The field is piecewise
+    linear in 11 x 512 ReLU units; a point whose pre-activation sits within fp32 rounding of a kink takes the other branch in a
+    different — equally valid — evaluation, and its direction jumps.  Written as data (fractions, worst cosine) per decoder."""
+    import copy
+    import json
+    out = {}
+    for D in (32, 64):
+        dec = build_decoder(R, D)
+        for prm in dec.parameters():
+            prm.requires_grad = False
+        lat = rnd((1, D), 40 + D, 0.8)
+        pts = torch.rand(4096, 3, generator=torch.Generator().manual_seed(41 + D)) * 2 - 1
+        g32 = R.meshudf.sample_grads(make_ref_udf(R, dec, lat), pts, 2 ** 12)
+        dec64 = copy.deepcopy(dec).double()
+        g64 = R.meshudf.sample_grads(make_ref_udf(R, dec64, lat.double()), pts.double(), 2 ** 12)
+        cos = (g32.double() * g64.double()).sum(-1)
+        ok = g64.norm(dim=-1) > 0.5
+        cos = cos[ok]
+        out[f"D{D}"] = {"points": int(ok.sum()), "frac_cos_le_1m1e-5": float((cos <= 1 - 1e-5).double().mean()),
+                        "frac_cos_le_1m1e-3": float((cos <= 1 - 1e-3).double().mean()), "worst_cosine": float(cos.min()),
+                        "median_one_minus_cos": float((1 - cos).median())}
+        print(f"  D={D}: reference fp32 autograd vs fp64 on {int(ok.sum())} points: cos <= 1-1e-5 on "
+              f"{100 * out[f'D{D}']['frac_cos_le_1m1e-5']:.3f} %, worst cosine {out[f'D{D}']['worst_cosine']:.6f}")
+    out["what"] = ("reference meshudf.sample_grads in fp32 (as the reference runs it) against the same call on a .double() copy of the decoder, "
+                   "G8 points (4096 uniform in [-1,1]^3), synthetic decoder weights; cosine between the two -normalize(grad) vectors")
+    path = os.path.join(OUT, "g8_direction_flips.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(f"  wrote {path}")
+
+
 def sha(t: torch.Tensor) -> str:
     return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
 
@@ -637,7 +669,7 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     R = import_reference(a.ref)
-    jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R),
+    jobs = {"g1": lambda: g1_g2(R), "g3": lambda: g3_g4(R), "g5": lambda: g5_g6(R), "g7": lambda: g7_g8(R), "g8flips": lambda: g8_direction_flips(R),
             "g9": lambda: g9(R), "g10": lambda: g10(R, [int(s) for s in a.g10_sizes.split(",")]),
             "g9d64": lambda: g9_d64(R), "g11": lambda: g11_conditioned_loops(R), "g12": lambda: g12_contractive(R),
             "g13": lambda: g13_marching_cubes(R, a.mc512), "g13luts": lambda: g13_lut_hashes(R), "g15": lambda: g15_image_preprocess(R), "g16": lambda: g16_clip_towers(R), "g17": lambda: g17_spatial_transformer(R), "g14": lambda: g14_cross_attention(R)}
