@@ -1201,7 +1201,11 @@ __device__ __forceinline__ void load_wstage8(f16x8 (&dst)[2][2], const _Float16 
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
+#if defined(SURFD_DEC_W_NT) && SURFD_DEC_W_NT        // experiment: weight planes with the non-temporal policy
+            dst[nt][q] = __builtin_nontemporal_load(reinterpret_cast<const gf16x8 *>(wb + (size_t)(nt * KS * 2048) + (lofs + (unsigned)((ks * 2 + q) * 1024))));
+#else
             dst[nt][q] = *reinterpret_cast<const gf16x8 *>(wb + (size_t)(nt * KS * 2048) + (lofs + (unsigned)((ks * 2 + q) * 1024)));
+#endif
 }
 
 __device__ __forceinline__ void mfma_step8(const f16x8 (&a)[2][2], const f16x8 (&b)[2][2], f32x16 (&acc)[2][2]) {
