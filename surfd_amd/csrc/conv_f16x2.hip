@@ -90,6 +90,7 @@ constexpr int C2_D = 2;    // ring stages; with 4 k16 steps per stage 16 x 1 KB 
 #ifndef SURFD_C2_LEAN_WAVES
 #define SURFD_C2_LEAN_WAVES 3          // waves per SIMD (= workgroups per CU) the lean form is compiled for: 3 -> 168 VGPRs, no spills
 #endif
+constexpr int C2_PLANE_NT2 = 13056;    // two column tiles per wave: 96 positions x (128 + 8) halfs; 2 planes + flag = 52 240 B, three workgroups per CU
 constexpr int C2_PLANE_LEAN = 10112;   // halfs per fp16 plane of the slab in the lean form: 2 planes + flag = 40 464 B, four workgroups per CU
 
 __device__ __forceinline__ float silu2(float v) { return v * __frcp_rn(1.f + __expf(-v)); }
@@ -111,9 +112,18 @@ __device__ __forceinline__ void lds_bar() {
 //       64-position layers in the wide form (L = 64 latents: configurations C4 / C5): a workgroup stages the whole 64-position row of
 //       ONE sample (GroupNorm needs it) and computes one 32-column half of it (A.nhalf = 2); with VEC = 16 the exchange arrays
 //       alias the slab as in the lean form, which keeps two such workgroups on a CU.
-template <int VEC, bool PREF, bool WT = false, bool LEAN = false, bool LF = false>
+// NT2  (lean form only; loops designed for >= 128 latents): TWO 32-column tiles per wave on K blocks of <= 128 channels.  The
+//       operand of a K block is staged by two threads per channel (thread = (channel, half of the batch rows), 32 values each as
+//       before), so a block of 112 channels x 64 columns costs what 224 x 32 cost — same LDS, same registers — but every
+//       weight fragment now feeds six matrix instructions instead of three and the fixed phases of a workgroup's life (argument
+//       fetch, split-K hand-off, epilogue) are paid once per 64 columns.  Needs its own weight packing (K blocks of <= 128
+//       channels: conv2_plan_layout's second layout).
+template <int VEC, bool PREF, bool WT = false, bool LEAN = false, bool LF = false, bool NT2 = false>
 __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT ? 2 : 1) : 2)) void conv2_kernel(Conv2Args A) {
     static_assert(!LEAN || (WT && VEC == 8 && !PREF), "lean form: wide decomposition, rows of <= 32 positions, no operand prefetch");
+    static_assert(!NT2 || (LEAN && !LF), "two column tiles per wave: lean form only");
+    constexpr int NCT = NT2 ? 2 : 1;      // column tiles a wave accumulates
+    constexpr int EXS = NT2 ? 128 : 256;  // row stride of the GroupNorm exchange arrays = threads that own a channel
     // the register / LDS diet of the lean form, also applied to 64-position rows in the wide form (16 float4 of operand per
     // thread: without it the kernel spills 77 registers at two workgroups per CU)
     constexpr bool SLIM = LEAN || (WT && VEC == 16);
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
     float *ex_mean = reinterpret_cast<float *>(lds_raw + (ALIAS ? 0 : A.off_ex));     // [VEC][256]
-    float *ex_m2 = ex_mean + VEC * 256;                                 // [VEC][256]
+    float *ex_m2 = ex_mean + VEC * 256;                                 // [VEC][256]  (NT2: [16 rows][128 channels])
     float *gstat = ex_m2 + VEC * 256;                                   // [nb * groups][2]
     float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag (lean form: the flag alone)
 
@@ -184,26 +194,37 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     const int KP = 1 << log2kp;
     const int ct = (WT || nct == 1) ? 0 : (wave & 1);
     const int kpart = WT ? 0 : (nct == 1) ? wave : (wave >> 1);
-    int colb, coll;
-    {
-        int m = ct * 32 + (lane & 31);
+    // staging ownership: thread <-> channel (NT2: thread <-> (channel, half of the batch rows))
+    const int cthr = NT2 ? (tid & 127) : tid;
+    const int rhalf = NT2 ? (tid >> 7) : 0;
+    int colb[NCT], coll[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+        int m = (NT2 ? t : ct) * 32 + (lane & 31);
         if (m >= M) m = 0;
         m += m_off;
-        colb = m >> A.log2Lout;
-        coll = m & (A.Lout - 1);
+        colb[t] = m >> A.log2Lout;
+        coll[t] = m & (A.Lout - 1);
     }
     const int nblk0 = A.seg[0].nblk;
     const int nch = nblk0 + (A.nseg > 1 ? A.seg[1].nblk : 0);
     // the low fp16 plane of the slab sits PLANE halfs behind the high one: a compile-time LDS offset
-    constexpr int PLANE = LEAN ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 15360);
+    constexpr int PLANE = NT2 ? C2_PLANE_NT2 : LEAN ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 15360);
     const int cs = A.cs;
     const float inv_sc = A.inv_sc;
 
     // two accumulators: the two small cross terms (xl*wh, xh*wl) share one, the main term has its own; a third
     // would push the kernel over 256 VGPRs (2 workgroups per CU) and make the compiler spill a just-loaded value
-    f32x16 acc_hh, acc_sm;
+    // (NT2: ONE accumulator per column tile — the two tiles' products interleave, so consecutive matrix instructions still never
+    //  wait on each other — and no second set of 32 registers)
+    f32x16 acc_hh[NCT], acc_sm[NT2 ? 1 : NCT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_hh[r] = 0.f; acc_sm[r] = 0.f; }
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_hh[t][r] = 0.f;
+    if constexpr (!NT2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_sm[0][r] = 0.f;
 
     // ---- weight stream state of one K block for this wave ------------------------------------------
     // Every wave of the workgroup runs the SAME static schedule (ngroups is wave-uniform; a wave whose k-part is
@@ -249,12 +270,13 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         const int bi = ch - (s ? nblk0 : 0);
         const int lv = A.seg[s].log2Lin - 2;          // log2(float4 per row)
         const int Lin = A.seg[s].Lin;
-        const int cg = min(bi * A.seg[s].blk + tid, A.seg[s].C - 1);
+        const int cg = min(bi * A.seg[s].blk + cthr, A.seg[s].C - 1);
         const float *src = A.seg[s].x + (long)cg * Lin;
         const long bstride = A.seg[s].bstride;
+        const int rowbase = rhalf * ((VEC * 4) >> A.seg[s].log2Lin);      // first batch row this thread stages (NT2: second half of the rows)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const int i = min(j >> lv, nb - 1), jj = j & ((1 << lv) - 1);
+            const int i = min(rowbase + (j >> lv), nb - 1), jj = j & ((1 << lv) - 1);
             v[j] = *reinterpret_cast<const f32x4 *>(src + (b0 + i) * bstride + 4 * jj);
         }
         ga = A.seg[s].gamma[cg]; be = A.seg[s].beta[cg];      // segments without GroupNorm point these at the bias vector
@@ -271,8 +293,8 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     // ---- epilogue operands (bias + per-(step, sample) embedding + residual), requested now, used at the end ----
     // kept as three separate register sets and only combined in the epilogue: combining them here would put a
     // wait for the (HBM-resident) embedding rows in front of the first K block
-    f32x4 pre_b[4], pre_e[4];
-    float pre_r[16];
+    f32x4 pre_b[4], pre_e[NCT][4];
+    float pre_r[NCT][16];
     const float *embp = A.emb;                        // never null: the host points unused operands at the bias vector
     if (A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;   // scalar load, requested here, first used by request_epilogue
     // head of a fused loop: the loop record, the iteration and its coefficient row are requested now — behind the operand and
@@ -287,18 +309,21 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         for (int q = 0; q < 5; ++q) lfrow[q] = lfv.tab[(long)lfk * 8 + q];
     }
     auto request_epilogue = [&]() {
-        const int m = min(ct * 32 + (lane & 31), M - 1) + m_off;
-        const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
         const int cmax4 = ((A.Cout + 3) & ~3) - 4;     // last aligned float4 of the (4-padded) per-channel vectors
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cob = min(tile * 32 + 8 * q + 4 * (lane >> 5), cmax4);      // rows frag_row(4q .. 4q+3, lane)
-            pre_b[q] = *reinterpret_cast<const f32x4 *>(A.bias + cob);
-            pre_e[q] = *reinterpret_cast<const f32x4 *>(embp + b * A.emb_bstride + cob);
+        for (int t = 0; t < NCT; ++t) {
+            const int m = min((NT2 ? t : ct) * 32 + (lane & 31), M - 1) + m_off;
+            const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int co = min(cob + k, A.Cout - 1);
-                pre_r[4 * q + k] = A.res[b * A.res_bstride + (long)co * A.res_cstride + l * A.res_lstride];
+            for (int q = 0; q < 4; ++q) {
+                const int cob = min(tile * 32 + 8 * q + 4 * (lane >> 5), cmax4);      // rows frag_row(4q .. 4q+3, lane)
+                if (t == 0) pre_b[q] = *reinterpret_cast<const f32x4 *>(A.bias + cob);
+                pre_e[t][q] = *reinterpret_cast<const f32x4 *>(embp + b * A.emb_bstride + cob);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int co = min(cob + k, A.Cout - 1);
+                    pre_r[t][4 * q + k] = A.res[b * A.res_bstride + (long)co * A.res_cstride + l * A.res_lstride];
+                }
             }
         }
     };
@@ -314,8 +339,9 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             const int lv = A.seg[s].log2Lin - 2, vpr = 1 << lv;
             const int Lin = A.seg[s].Lin;
             const int blk = A.seg[s].blk, blkp = A.seg[s].blkp;
-            const int c = tid, cg = bi * blk + c;
+            const int c = cthr, cg = bi * blk + c;
             const bool cok = c < blk;
+            const int rowbase = rhalf * ((VEC * 4) >> A.seg[s].log2Lin);
             const int pad = A.seg[s].taps == 3 ? 1 : 0;
             const int ups = A.seg[s].ups, act = A.seg[s].act;
             if (A.seg[s].gn) {
@@ -354,9 +380,9 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                 tree(rm2);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
-                    if ((j & (vpr - 1)) == 0 && (j >> lv) < nb) {     // first float4 of a live row (uniform)
-                        ex_mean[(j >> lv) * 256 + c] = rs[j];
-                        ex_m2[(j >> lv) * 256 + c] = rm2[j];
+                    if ((j & (vpr - 1)) == 0 && rowbase + (j >> lv) < nb) {     // first float4 of a live row (uniform per wave)
+                        ex_mean[(rowbase + (j >> lv)) * EXS + c] = rs[j];
+                        ex_m2[(rowbase + (j >> lv)) * EXS + c] = rm2[j];
                     }
                 lds_bar();
                 C2_STAMP_FIRST(2);
@@ -369,8 +395,8 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     const bool qok = q < nq;
                     const int i = qok ? q / ng : 0;
                     const int g = qok ? q - i * ng : 0;
-                    const float *pm = ex_mean + i * 256 + g * gs;
-                    const float *p2 = ex_m2 + i * 256 + g * gs;
+                    const float *pm = ex_mean + i * EXS + g * gs;
+                    const float *p2 = ex_m2 + i * EXS + g * gs;
                     float sm = 0.f;
                     if (qok)
                         for (int k = lt; k < gs; k += 8) sm += pm[k];
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     const int gq = min(c, blk - 1) / gs;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
-                        const int i = j >> lv;
+                        const int i = rowbase + (j >> lv);
                         const int q = (i < nb) ? i * ng + gq : 0;
                         gmr[j] = gstat[2 * q]; gscr[j] = ga * gstat[2 * q + 1];
                     }
@@ -426,7 +452,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                 float amax = 0.f;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const int i = j >> lv, jj = j & (vpr - 1);
+                    const int i = rowbase + (j >> lv), jj = j & (vpr - 1);
                     if (i < nb) {
                         _Float16 *row = slab + (i * A.Lsl + pad + rstep * 4 * jj) * cs + c;
 #pragma unroll
@@ -466,7 +492,9 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         if constexpr (PREF) issue_operand(has_next ? chn : ch, vn, gan, ben);      // unconditional (re-reads this block at the end)
         {
             const int s = ch >= nblk0 ? 1 : 0;
-            const int lbase = (colb * A.Lsl + coll * A.seg[s].stride) * cs + 8 * (lane >> 5);
+            int lbase[NCT];
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) lbase[t] = (colb[t] * A.Lsl + coll[t] * A.seg[s].stride) * cs + 8 * (lane >> 5);
             const int nk = cur.nk;
             auto compute = [&](const f16x8 (&a)[C2_U][2], int g) {
 #pragma unroll
@@ -474,16 +502,30 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     const int it = cur.it_beg + g * C2_U + u;
                     if (it < cur.it_end) {          // wave-uniform (scalar branch); only LDS reads and MFMAs inside: vmcnt bookkeeping unaffected
                         const int tap = (it >= nk) + (it >= 2 * nk);
-                        const _Float16 *bp = slab + lbase + tap * cs + (it - tap * nk) * 16;
+                        const int koff = tap * cs + (it - tap * nk) * 16;
+                        if constexpr (NT2) {
+                            const _Float16 *bp0 = slab + lbase[0] + koff, *bp1 = slab + lbase[NCT - 1] + koff;
+                            const f16x8 bh0 = *reinterpret_cast<const f16x8 *>(bp0), bh1 = *reinterpret_cast<const f16x8 *>(bp1);
+                            const f16x8 bl0 = *reinterpret_cast<const f16x8 *>(bp0 + PLANE), bl1 = *reinterpret_cast<const f16x8 *>(bp1 + PLANE);
+                            // small terms first, the two column tiles alternating
+                            acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh0, acc_hh[0], 0, 0, 0);
+                            acc_hh[NCT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh1, acc_hh[NCT - 1], 0, 0, 0);
+                            acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl0, acc_hh[0], 0, 0, 0);
+                            acc_hh[NCT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl1, acc_hh[NCT - 1], 0, 0, 0);
+                            acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh0, acc_hh[0], 0, 0, 0);
+                            acc_hh[NCT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh1, acc_hh[NCT - 1], 0, 0, 0);
+                        } else {
+                        const _Float16 *bp = slab + lbase[0] + koff;
                         const f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
                         const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + PLANE);
 #if defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 1      // developer aid: no matrix work (operands still fetched)
-                        acc_sm[0] += (float)a[u][1][0] + (float)bh[0]; acc_hh[0] += (float)a[u][0][0] + (float)bl[0];
+                        acc_sm[0][0] += (float)a[u][1][0] + (float)bh[0]; acc_hh[0][0] += (float)a[u][0][0] + (float)bl[0];
 #else
-                        acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_sm, 0, 0, 0);
-                        acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh, 0, 0, 0);
-                        acc_sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm, 0, 0, 0);
+                        acc_sm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_sm[0], 0, 0, 0);
+                        acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh[0], 0, 0, 0);
+                        acc_sm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm[0], 0, 0, 0);
 #endif
+                        }
                     }
                 }
             };
@@ -527,22 +569,24 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     C2_STAMP(6);
 
     // ---- sum the two product streams, then the k-parts of the workgroup (LDS) ------------------------
-    f32x16 acc;
+    f32x16 acc[NCT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acc_sm[r] + acc_hh[r];
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = NT2 ? acc_hh[t][r] : acc_sm[0][r] + acc_hh[t][r];
     if constexpr (!WT) {
         lds_bar();
         if (kpart > 0) {
             float *dst = red + ((kpart - 1) * nct + ct) * 1024;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+            for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[0][r];
         }
         lds_bar();
         if (kpart == 0) {
             for (int kp = 1; kp < KP; ++kp) {
                 const float *srcp = red + ((kp - 1) * nct + ct) * 1024;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] += srcp[r * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[0][r] += srcp[r * 64 + lane];
             }
         }
     }
@@ -555,11 +599,13 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         float *mine = A.part + (((size_t)kz * A.nby + by) * A.ntiles + tile) * A.part_stride;
         if (owner) {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 val = {acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
-                float *dst = mine + ((size_t)(ct * 4 + r4) * 64 + lane) * 4;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(val) : "memory");
-            }
+            for (int t = 0; t < NCT; ++t)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 val = {acc[t][4 * r4], acc[t][4 * r4 + 1], acc[t][4 * r4 + 2], acc[t][4 * r4 + 3]};
+                    float *dst = mine + ((size_t)((NT2 ? t : ct) * 4 + r4) * 64 + lane) * 4;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(val) : "memory");
+                }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -577,29 +623,35 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         if (*flag == 0) return;
         if (owner) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int t = 0; t < NCT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             for (int z = 0; z < A.KS; ++z) {
                 const float *src = A.part + (((size_t)z * A.nby + by) * A.ntiles + tile) * A.part_stride;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x4 pv = *reinterpret_cast<const f32x4 *>(src + ((size_t)(ct * 4 + r4) * 64 + lane) * 4);
+                for (int t = 0; t < NCT; ++t)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[4 * r4 + q] += pv[q];
-                }
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4 *>(src + ((size_t)((NT2 ? t : ct) * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[t][4 * r4 + q] += pv[q];
+                    }
             }
         }
     }
     C2_STAMP(8);
     // ---- epilogue ---------------------------------------------------------------------------------------
-    if (owner) {
-        const int ml = ct * 32 + (lane & 31), m = ml + m_off;
+    if (owner)
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+        const int ml = (NT2 ? t : ct) * 32 + (lane & 31), m = ml + m_off;
         const bool mok = ml < M;
         const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = tile * 32 + frag_row(r, lane);
             if (mok && co < A.Cout) {
-                const float val = acc[r] * inv_sc + ((pre_b[r >> 2][r & 3] + (A.has_emb ? pre_e[r >> 2][r & 3] : 0.f)) + (A.has_res ? pre_r[r] : 0.f));
+                const float val = acc[t][r] * inv_sc + ((pre_b[r >> 2][r & 3] + (A.has_emb ? pre_e[t][r >> 2][r & 3] : 0.f)) + (A.has_res ? pre_r[t][r] : 0.f));
                 A.out[b * A.out_bstride + (long)co * A.Lout + l] = val;
                 if constexpr (LF) {
                     // x0 prediction -> x_{t-1}, in place (this element of x is read and written by this thread only)
@@ -714,8 +766,30 @@ static bool seg_blocking(const SegPlan &sp, int &blk, int &blkp, int &nblk) {
     return true;
 }
 
+// K blocking for the two-column-tile form: <= 128 channels per block (two staging threads per channel), whole GroupNorm
+// groups, a power-of-two number of the 32 groups per block so that the blocks tile the channel axis
+static bool seg_blocking2(const SegPlan &sp, int &blk, int &blkp, int &nblk) {
+    const int C = sp.C;
+    blk = 0;
+    if (sp.gn) {
+        if (C % 32) return false;
+        const int gs = C / 32;
+        if (gs > 128) return false;
+        int m = 32;
+        while (m > 1 && gs * m > 128) m >>= 1;
+        blk = gs * m;
+    } else {
+        for (int b = std::min(128, C); b >= 1; --b)
+            if (C % b == 0 && (b % 16 == 0 || b == C)) { blk = b; break; }
+        if (!blk || (blk < 64 && C > 128)) return false;
+    }
+    blkp = ceil_div(blk, 16) * 16;
+    nblk = C / blk;
+    return true;
+}
+
 int conv2_plan_layout(surfd_unet *u) {
-    size_t off = 0;
+    size_t off = 0, off2 = 0;
     int nsc = 0, id = 0;
     for (auto &op : u->ops) {
         if (op.kind != 0) continue;
@@ -733,14 +807,28 @@ int conv2_plan_layout(surfd_unet *u) {
         c.whf_off = off;
         off += (size_t)ceil_div(c.Cout, 32) * k16 * 1024;
         c.sc_idx = nsc++;
+        c.f16_ok2 = 1;
+        int k16b = 0;
+        for (int s = 0; s < c.nseg; ++s) {
+            if (!seg_blocking2(c.seg[s], c.blk2[s], c.blkp2[s], c.nblk2[s])) { c.f16_ok2 = 0; break; }
+            c.k16_off2[s] = k16b;
+            k16b += c.nblk2[s] * c.seg[s].taps * (c.blkp2[s] / 16);
+        }
+        if (c.f16_ok2) {
+            c.KS16_2 = k16b;
+            c.whf2_off = off2;
+            off2 += (size_t)ceil_div(c.Cout, 32) * k16b * 1024;
+        }
     }
     u->whf_halfs = off;
+    u->whf2_halfs = off2;
     u->n_sc = nsc;
     return SURFD_OK;
 }
 
 int conv2_finalize(surfd_unet *u, hipStream_t st) {
     if (!u->whf_halfs) return SURFD_OK;
+    if (!u->whf2 && u->whf2_halfs) HIP_TRY(hipMalloc((void **)&u->whf2, u->whf2_halfs * sizeof(_Float16)));
     if (!u->whf) {
         HIP_TRY(hipMalloc((void **)&u->whf, u->whf_halfs * sizeof(_Float16)));
         HIP_TRY(hipMalloc((void **)&u->wsc, (size_t)u->n_sc * 4 * sizeof(float)));
@@ -770,6 +858,14 @@ int conv2_finalize(surfd_unet *u, hipStream_t st) {
                            (const float *)(u->wpack + c.w_off), c.KGtot, ntiles, ps[0], ps[1], c.nseg, c.KS16,
                            (const float *)sc, u->whf + c.whf_off);
         LAUNCH_CHECK();
+        if (c.f16_ok2) {          // the same scaled weights in the second K blocking
+            for (int s = 0; s < c.nseg; ++s) { ps[s].blk = c.blk2[s]; ps[s].blkp = c.blkp2[s]; ps[s].k16_off = c.k16_off2[s]; }
+            const long total2 = (long)ntiles * c.KS16_2 * 512;
+            hipLaunchKernelGGL(c2_pack_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(total2, 256), 4096)), dim3(256), 0, st,
+                               (const float *)(u->wpack + c.w_off), c.KGtot, ntiles, ps[0], ps[1], c.nseg, c.KS16_2,
+                               (const float *)sc, u->whf2 + c.whf2_off);
+            LAUNCH_CHECK();
+        }
     }
     // the kernels take 1/SC by value (launch_conv2): one read-back per finalize
     u->wsc_host.assign((size_t)u->n_sc * 4, 0.f);
@@ -800,6 +896,11 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         else { ptr = const_cast<float *>(io.ext_in); bs = io.ext_in_bs; }
     };
     const bool wide = u->wide_batch > 0;
+    // two column tiles per wave (second weight layout): loops designed for >= 128 latents, stride-1 layers of <= 32 positions
+    static const int nt2_env = env_int("SURFD_CONV2_NT2", 1), nt2_min = env_int("SURFD_CONV2_NT2_MIN", 128);
+    bool nt2 = wide && nt2_env && u->wide_batch >= nt2_min && c.f16_ok2 && u->whf2 && !(io.lf && c.dst.buf == -3) && A.Lout <= 32;
+    for (int s = 0; s < c.nseg && nt2; ++s)
+        nt2 = c.seg[s].stride == 1 && !c.seg[s].ups && c.seg[s].ds == c.ds_out && c.seg[s].ds != 0;
     int Lin0 = 0, max_lsl = 1, max_blkp = 16;
     for (int s = 0; s < c.nseg; ++s) {
         const SegPlan &sp = c.seg[s];
@@ -819,6 +920,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
             S.gs = sp.C / 32;
         }
         S.blk = c.blk[s]; S.blkp = c.blkp[s]; S.nblk = c.nblk[s]; S.k16_off = c.k16_off[s];
+        if (nt2) { S.blk = c.blk2[s]; S.blkp = c.blkp2[s]; S.nblk = c.nblk2[s]; S.k16_off = c.k16_off2[s]; }
         const int lsl = sp.taps == 3 ? (sp.stride == 2 ? 2 * A.Lout + 1 : A.Lout + 2) : A.Lout;
         max_lsl = std::max(max_lsl, lsl);
         max_blkp = std::max(max_blkp, S.blkp);
@@ -833,15 +935,16 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     static const int lean_env = env_int("SURFD_CONV2_LEAN", 1);      // 0: the two-workgroups-per-CU wide kernel (A/B timing)
     const bool fuse_head = io.lf && c.dst.buf == -3;                 // 80 workgroups, once per evaluation: keeps the 256-register form (no spills with the loop record live)
     // lean form (three workgroups per CU) wherever one batch entry's slab fits its 20 KB planes
-    const bool lean = wt && VEC == 8 && lean_env && !fuse_head && (size_t)A.Lsl * (max_blkp + 8) <= (size_t)C2_PLANE_LEAN;
-    const int nb_cap = split ? 1 : std::min({(VEC * 4) / Lin0, std::max(1, (wt ? 32 : 64) / A.Lout), 8});
+    nt2 = nt2 && wt && VEC == 8 && lean_env;
+    const bool lean = nt2 || (wt && VEC == 8 && lean_env && !fuse_head && (size_t)A.Lsl * (max_blkp + 8) <= (size_t)C2_PLANE_LEAN);
+    const int nb_cap = nt2 ? std::max(1, 64 / A.Lout) : split ? 1 : std::min({(VEC * 4) / Lin0, std::max(1, (wt ? 32 : 64) / A.Lout), 8});
     int nb = std::min(B, nb_cap);
     // one fp16 plane of the slab has a fixed size (the kernel addresses the low plane with an immediate): 30 KB
     // (36 KB for 64-long rows), i.e. <= 78 KB of LDS per workgroup so that two of them share a CU
-    const size_t plane_halfs = lean ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 15360);
+    const size_t plane_halfs = nt2 ? C2_PLANE_NT2 : lean ? C2_PLANE_LEAN : (VEC == 16 ? 18432 : 15360);
     while (nb > 1 && (size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) --nb;
     if ((size_t)nb * A.Lsl * (max_blkp + 8) > plane_halfs) return 1;
-    if (!split && nb * A.Lout > (wt ? 32 : 64)) return 1;
+    if (!split && nb * A.Lout > ((wt && !nt2) ? 32 : 64)) return 1;
     A.nhalf = split ? 2 : 1;
     A.bchunk = nb;
     A.cs = max_blkp + 8;
@@ -857,6 +960,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     lds += (size_t)lds_extra;
     if (lds > 160 * 1024) return 1;
     A.whf = u->whf + c.whf_off; A.KS16 = c.KS16;
+    if (nt2) { A.whf = u->whf2 + c.whf2_off; A.KS16 = c.KS16_2; }
     A.sc = u->wsc + (size_t)c.sc_idx * 4;
     A.inv_sc = u->wsc_host[(size_t)c.sc_idx * 4 + 1];
     A.bias = u->vecs + c.bias_off;
@@ -875,7 +979,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.ntiles = ceil_div(c.Cout, 32);
     A.nby = ceil_div(B, nb) * A.nhalf;
     // K slices over workgroups when (tiles x batch chunks) under-fills the chip: whole K blocks per slice
-    const int nch = c.nblk[0] + (c.nseg > 1 ? c.nblk[1] : 0);
+    const int nch = nt2 ? c.nblk2[0] + (c.nseg > 1 ? c.nblk2[1] : 0) : c.nblk[0] + (c.nseg > 1 ? c.nblk[1] : 0);
     static const int ks_fill_env = env_int("SURFD_CONV2_FILL", 0);
     // workgroups aimed at: as many as fit the chip at once — two per CU (measured: 1.555 -> 1.472 ms per evaluation), three in the
     // lean form (80 latents, design batch 80: 2.49 -> 2.43 ms per evaluation alone, 2 x 80: 21.6 -> 20.6 us per evaluation and latent)
@@ -885,7 +989,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     const int base = A.ntiles * A.nby;
     A.nrt = wt ? ceil_div(A.ntiles, 4) : A.ntiles;
     int KS = 1;
-    A.part_stride = wt ? 1024 : 2 * 1024;      // floats per partial tile: one column tile (wide form) or up to two
+    A.part_stride = (wt && !nt2) ? 1024 : 2 * 1024;      // floats per partial tile: one column tile (wide form) or up to two
     if (wide) {
         // the K split is a function of the LAYER and of the handle's design batch only — never of B — so that a latent's
         // result does not depend on the width of the batch it rides in
@@ -928,6 +1032,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, false, false, true>), grid, dim3(256), lds, st, A);
         else hipLaunchKernelGGL((conv2_kernel<8, false, false, false, true>), grid, dim3(256), lds, st, A);
     }
+    else if (nt2) hipLaunchKernelGGL((conv2_kernel<8, false, true, true, false, true>), grid, dim3(256), lds, st, A);
     else if (lean) hipLaunchKernelGGL((conv2_kernel<8, false, true, true>), grid, dim3(256), lds, st, A);
     else if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true>), grid, dim3(256), lds, st, A);
     else if (wt && wpref) hipLaunchKernelGGL((conv2_kernel<8, true, true>), grid, dim3(256), lds, st, A);
@@ -947,6 +1052,7 @@ int conv2_set_attributes() {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<8, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_kernel<16, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));

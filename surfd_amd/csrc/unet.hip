@@ -1054,7 +1054,7 @@ void surfd_unet_destroy(surfd_unet *u) {
     if (u->t_dev) (void)hipFree(u->t_dev);
     if (u->part) (void)hipFree(u->part);
     if (u->counters) (void)hipFree(u->counters);
-    for (void *p : {(void *)u->whf, (void *)u->wsc, (void *)u->sat}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)u->whf, (void *)u->whf2, (void *)u->wsc, (void *)u->sat}) if (p) (void)hipFree(p);
     if (u->loop.exec) (void)hipGraphExecDestroy(u->loop.exec);
     if (u->loop.graph) (void)hipGraphDestroy(u->loop.graph);
     if (u->loop.cap_stream) (void)hipStreamDestroy(u->loop.cap_stream);

@@ -41,6 +41,12 @@ struct ConvPlan {
     size_t whf_off = 0;        // halfs
     int sc_idx = -1;           // slot in surfd_unet::wsc ({SC, 1/SC, max|W| bits, pad})
     int id = -1;               // index among the conv ops of the denoiser body (debugging aid)
+    // second f16x2 layout of the same weights: K blocks of <= 128 channels (whole GroupNorm groups) for the two-column-tile
+    // form of the wide kernel (conv_f16x2.hip, NT2); f16_ok2 = 0: the layer has no such blocking
+    int f16_ok2 = 0;
+    int blk2[2] = {0, 0}, blkp2[2] = {0, 0}, nblk2[2] = {0, 0}, k16_off2[2] = {0, 0};
+    int KS16_2 = 0;
+    size_t whf2_off = 0;
 };
 
 struct AttnPlan { View qkv, out; int C = 0, ds = 1; };
@@ -83,6 +89,7 @@ struct surfd_unet {
     int *counters = nullptr;
     // f16x2 conv path (conv_f16x2.hip)
     _Float16 *whf = nullptr; size_t whf_halfs = 0;     // split-fp16 weight planes, fragment-major for the 32x32x16 MFMA
+    _Float16 *whf2 = nullptr; size_t whf2_halfs = 0;   // the same weights in K blocks of <= 128 channels (two-column-tile form)
     float *wsc = nullptr; int n_sc = 0;                // per-layer power-of-two weight scale
     std::vector<float> wsc_host;                       // host copy of wsc (the conv kernel takes 1/SC by value)
     unsigned *sat = nullptr;                           // device counter: workgroups that clamped an operand to the fp16 range

@@ -479,7 +479,8 @@ def wide_model(request):
         model.set_wide(0)
 
 
-@pytest.mark.parametrize("B,L", [(1, 32), (8, 32), (5, 64), (2, 8), (16, 16), (40, 32), (80, 32), (80, 64), (160, 32)])   # 80 = the width the bench rides
+@pytest.mark.parametrize("wide_model", [32, 160], indirect=True)
+@pytest.mark.parametrize("B,L", [(1, 32), (8, 32), (5, 64), (2, 8), (16, 16), (40, 32), (80, 32), (80, 64), (160, 32), (3, 16), (33, 8)])   # 80 = the width the bench rides
 def test_wide_form_forward_vs_oracle(wide_model, B, L):
     model, _, sd = wide_model
     g = torch.Generator().manual_seed(B * 100 + L)
@@ -495,7 +496,7 @@ def test_wide_form_forward_vs_oracle(wide_model, B, L):
     assert model.saturation_count() == 0
 
 
-@pytest.mark.parametrize("wide_model", [32, 80], indirect=True)
+@pytest.mark.parametrize("wide_model", [32, 80, 160], indirect=True)      # 160: two column tiles per wave on 112-channel K blocks (NT2)
 def test_wide_form_vs_golden_modules_and_chain(wide_model, golden):
     """The wide form against the same reference-made fixtures as the latency form: whole forward (G3), per-module
     activations (G4) and the 1000-step contractive chain end to end (G12)."""
@@ -524,6 +525,7 @@ def test_wide_form_vs_golden_modules_and_chain(wide_model, golden):
         cm.set_wide(0)
 
 
+@pytest.mark.parametrize("wide_model", [32, 160], indirect=True)
 def test_wide_form_latent_does_not_depend_on_batch_width(wide_model):
     """A shape's latent is bit-identical whatever loop batch it rode in (noise is seeded per global shape index): the wide
     form's K split is a function of the layer, not of B.  40 DDIM steps amplify any last-bit difference."""
