@@ -127,7 +127,13 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     // the register / LDS diet of the lean form, also applied to 64-position rows in the wide form (16 float4 of operand per
     // thread: without it the kernel spills 77 registers at two workgroups per CU)
     constexpr bool SLIM = LEAN || (WT && VEC == 16);
-    constexpr int C2_U = SLIM ? 2 : 4;    // k16 steps per ring stage
+#ifndef SURFD_C2_LEAN_U
+#define SURFD_C2_LEAN_U 2
+#endif
+    // ONE accumulator per column tile (experiment SURFD_C2_LEAN_U=3: the 16 registers of the second one buy a third k16 step per
+    // ring stage in the lean form)
+    constexpr bool ONE_ACC = NT2 || (LEAN && SURFD_C2_LEAN_U == 3);
+    constexpr int C2_U = (LEAN && !NT2) ? SURFD_C2_LEAN_U : SLIM ? 2 : 4;    // k16 steps per ring stage
     constexpr bool ALIAS = SLIM;          // GroupNorm exchange arrays inside the (not yet written) slab
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
@@ -217,12 +223,12 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     // would push the kernel over 256 VGPRs (2 workgroups per CU) and make the compiler spill a just-loaded value
     // (NT2: ONE accumulator per column tile — the two tiles' products interleave, so consecutive matrix instructions still never
     //  wait on each other — and no second set of 32 registers)
-    f32x16 acc_hh[NCT], acc_sm[NT2 ? 1 : NCT];
+    f32x16 acc_hh[NCT], acc_sm[1];
 #pragma unroll
     for (int t = 0; t < NCT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_hh[t][r] = 0.f;
-    if constexpr (!NT2)
+    if constexpr (!ONE_ACC)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_sm[0][r] = 0.f;
 
@@ -521,9 +527,15 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #if defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 1      // developer aid: no matrix work (operands still fetched)
                         acc_sm[0][0] += (float)a[u][1][0] + (float)bh[0]; acc_hh[0][0] += (float)a[u][0][0] + (float)bl[0];
 #else
+                        if constexpr (ONE_ACC) {
+                            acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_hh[0], 0, 0, 0);
+                            acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_hh[0], 0, 0, 0);
+                            acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh[0], 0, 0, 0);
+                        } else {
                         acc_sm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][1], bh, acc_sm[0], 0, 0, 0);
                         acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh[0], 0, 0, 0);
                         acc_sm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm[0], 0, 0, 0);
+                        }
 #endif
                         }
                     }
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #pragma unroll
     for (int t = 0; t < NCT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = NT2 ? acc_hh[t][r] : acc_sm[0][r] + acc_hh[t][r];
+        for (int r = 0; r < 16; ++r) acc[t][r] = ONE_ACC ? acc_hh[t][r] : acc_sm[0][r] + acc_hh[t][r];
     if constexpr (!WT) {
         lds_bar();
         if (kpart > 0) {

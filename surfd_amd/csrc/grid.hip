@@ -823,7 +823,12 @@ int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, i
     const long upper = level == 0 ? io.n : capacity;
     hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(upper, 256), 4096)), dim3(256), 0, st, io, vals);
     LAUNCH_CHECK();
-    return refine_level_ordered(g, level, g->cur_udf, st);
+    if ((rc = refine_level_ordered(g, level, g->cur_udf, st))) return rc;
+    if (level == g->n_levels - 1 && !g->cur_grads) {      // a fill without gradients ends here (otherwise surfd_grid_shard_grad_commit does this)
+        g->dense_last = false;
+        return add_to_totals(g, 0, st);
+    }
+    return SURFD_OK;
 }
 
 int surfd_grid_shard_grad_eval(surfd_grid *g, surfd_decoder *d, int sample, int rank, int world, float *ngrads, int64_t capacity,

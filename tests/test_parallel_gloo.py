@@ -71,6 +71,22 @@ def _grid_run(N=64):
     return udf, g, stats
 
 
+def _tile_exchange(rank, world, n=1000, cap=2048, tile=64):
+    """The exchange protocol of the NATIVE grid-shard path (surfd_grid_shard_level_eval / GridFiller.fill_grid_sharded) on the
+    host: rank r fills the 64-point tiles r, r + world, ... of a zeroed fixed-capacity buffer indexed by point number, the
+    buffers are summed over the ranks (parallel.sum_over_ranks) — every entry is non-zero on exactly one rank, so the sum is the
+    gather, bit for bit, and entries beyond the level's length stay zero."""
+    from oracle import gridfiller as ogrid
+    from surfd_amd.parallel import sum_over_ranks
+    pts = torch.rand(n, 3, generator=torch.Generator().manual_seed(5)) * 2 - 1       # the same "level" on every rank
+    vals = torch.zeros(cap)
+    for t in range(rank, -(-n // tile), world):
+        lo, hi = t * tile, min((t + 1) * tile, n)
+        vals[lo:hi] = ogrid.analytic_field(pts[lo:hi])
+    sum_over_ranks(vals)
+    return vals.clone(), ogrid.analytic_field(pts)
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -79,7 +95,7 @@ def _worker(rank, world, port, out):
         lat, (first, count) = _run(TOTAL)
         toy, _ = _run(TOTAL, toy=True)
         gu, gg, gstats = _grid_run()
-        out[rank] = (lat.clone(), first, count, toy.clone(), gu.clone(), gg.clone(), gstats["fwd_per_level"])
+        out[rank] = (lat.clone(), first, count, toy.clone(), gu.clone(), gg.clone(), gstats["fwd_per_level"], _tile_exchange(rank, world))
     finally:
         dist.destroy_process_group()
 
@@ -102,3 +118,6 @@ def test_sharded_equals_single_process():
         # grid-shard mode: every rank ends with the single-process grid, bit for bit
         assert torch.equal(out[r][4], gu1) and out[r][6] == gstats1["fwd_per_level"]
         assert torch.equal(out[r][5], gg1)
+        # native grid-shard exchange: interleaved tiles + sum over the ranks == the whole level, the padding stays zero
+        vals, want = out[r][7]
+        assert torch.equal(vals[:want.shape[0]], want) and not vals[want.shape[0]:].any()
