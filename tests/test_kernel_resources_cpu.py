@@ -49,7 +49,7 @@ def test_gradient_decoder_kernel_spill_bound(meta):
 
 
 def test_conv_kernels_keep_two_workgroups_per_cu(meta):
-    for name in ("void surfd::conv2_kernel<8, false, false, false, false>", "void surfd::conv2_kernel<8, false, true, false, false>"):
+    for name in ("void surfd::conv2_kernel<8, false, false, false, false, false>", "void surfd::conv2_kernel<8, false, true, false, false, false>"):
         k = _one(meta, name)
         assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0
         assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256          # 2 waves per SIMD
@@ -59,7 +59,14 @@ def test_lean_conv_kernel_fits_three_workgroups_per_cu(meta):
     """The wide loops' default kernel (round 4): three 256-thread workgroups per CU need <= 168 registers per lane, no
     scratch (the build for four — 128 registers — spills 63 and measured 30 % slower), <= 112 SGPRs (the hardware admits
     floor(800 / (ceil(sgpr / 16) * 16 + 16)) blocks of 256 threads per CU)."""
-    k = _one(meta, "void surfd::conv2_kernel<8, false, true, true, false>")
+    k = _one(meta, "void surfd::conv2_kernel<8, false, true, true, false, false>")
     assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0
     assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 168
     assert k[".sgpr_count"] <= 112
+
+
+def test_two_column_tile_lean_kernel_fits_three_workgroups_per_cu(meta):
+    """NT2 (two column tiles per wave on <= 128-channel K blocks): same budget as the one-tile lean form; the two registers it
+    spills are outside the K loop."""
+    k = _one(meta, "void surfd::conv2_kernel<8, false, true, true, false, true>")
+    assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 168 and k[".vgpr_spill_count"] <= 4 and k[".private_segment_fixed_size"] <= 16
