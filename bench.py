@@ -104,8 +104,9 @@ def parse():
     ap.add_argument("--shard-path", choices=["native", "callback"], default="native",
                     help="grid-shard: native = surfd_grid_shard_* (voxel-ordered lists, tiles r, r + G, ... of every level, fixed-capacity buffers summed "
                          "over the ranks, no host read between levels); callback = round 3's ShardedField over the host-callback grid API")
-    ap.add_argument("--shard-capacity", type=int, default=1 << 24, help="grid-shard native: points a level's exchange buffer holds")
-    ap.add_argument("--shard-grad-capacity", type=int, default=1 << 21, help="grid-shard native: gradient points the exchange buffer holds")
+    ap.add_argument("--shard-capacity", type=int, default=0,
+                    help="grid-shard native: points a level's exchange buffer holds (0 = sized from the untimed shapes of the first step: 2 x their largest level, as a power of two)")
+    ap.add_argument("--shard-grad-capacity", type=int, default=0, help="grid-shard native: gradient points the exchange buffer holds (0 = sized the same way)")
     ap.add_argument("--batch-grids", type=int, default=1,
                     help="1: the grids of a step are refined together, one decoder launch per level for all shapes "
                          "(meshudf.fill_grids); 0: shape after shape")
@@ -837,6 +838,23 @@ def grid_shard_main(a, world, rank):
                 fwd_pts[0] += sum(filler.last_stats["fwd_per_level"])
         return lat
 
+    if a.shard_path == "native" and (a.shard_capacity <= 0 or a.shard_grad_capacity <= 0):
+        # exchange-buffer capacities from the field itself: one untimed shape with generous buffers, its device-side counts read
+        # once; every rank sees the same grid, hence the same counts and the same capacities (the collectives' sizes must agree)
+        lat0 = diffusion.p_sample_loop(model, (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise_bank[0], fused=True)
+        dec.bind_latents(lat0.reshape(B, a.latent))
+        top_f = top_g = 0
+        for k in range(B):          # the B shapes of the first step: fields differ, the capacities take the largest with a factor 2
+            filler.fill_grid_sharded(make_udf_func(dec, lat0[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=True,
+                                     capacity=min(1 << 26, 7 * (N // 2) ** 3), grad_capacity=min(1 << 25, N ** 3))
+            top_f, top_g = max(top_f, max(filler.last_stats["fwd_per_level"])), max(top_g, filler.last_stats["grad"])
+        pow2 = lambda v: 1 << max(16, int(2 * v - 1).bit_length())
+        if a.shard_capacity <= 0:
+            a.shard_capacity = pow2(top_f)
+        if a.shard_grad_capacity <= 0:
+            a.shard_grad_capacity = pow2(top_g)
+        filler._shard_buf = None
+        torch.cuda.empty_cache()
     for s in range(a.warmup):
         one_step(s)
     if filler._handle is not None:
