@@ -105,7 +105,7 @@ def parse():
                     help="grid-shard: native = surfd_grid_shard_* (voxel-ordered lists, tiles r, r + G, ... of every level, fixed-capacity buffers summed "
                          "over the ranks, no host read between levels); callback = round 3's ShardedField over the host-callback grid API")
     ap.add_argument("--shard-capacity", type=int, default=0,
-                    help="grid-shard native: points a level's exchange buffer holds (0 = sized from the untimed shapes of the first step: 2 x their largest level, as a power of two)")
+                    help="grid-shard native: points a level's exchange buffer holds (0 = sized from the untimed shapes of the first step: 2 x their largest level — 4 x for gradient points — as a power of two, at least 2^22 / 2^21)")
     ap.add_argument("--shard-grad-capacity", type=int, default=0, help="grid-shard native: gradient points the exchange buffer holds (0 = sized the same way)")
     ap.add_argument("--batch-grids", type=int, default=1,
                     help="1: the grids of a step are refined together, one decoder launch per level for all shapes "
@@ -848,11 +848,11 @@ def grid_shard_main(a, world, rank):
             filler.fill_grid_sharded(make_udf_func(dec, lat0[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=True,
                                      capacity=min(1 << 26, 7 * (N // 2) ** 3), grad_capacity=min(1 << 25, N ** 3))
             top_f, top_g = max(top_f, max(filler.last_stats["fwd_per_level"])), max(top_g, filler.last_stats["grad"])
-        pow2 = lambda v: 1 << max(16, int(2 * v - 1).bit_length())
+        pow2 = lambda v, floor: 1 << max(floor, int(v - 1).bit_length())
         if a.shard_capacity <= 0:
-            a.shard_capacity = pow2(top_f)
+            a.shard_capacity = pow2(2 * top_f, 22)
         if a.shard_grad_capacity <= 0:
-            a.shard_grad_capacity = pow2(top_g)
+            a.shard_grad_capacity = pow2(4 * top_g, 21)         # the near-surface count varies most from shape to shape
         filler._shard_buf = None
         torch.cuda.empty_cache()
     for s in range(a.warmup):
@@ -866,6 +866,8 @@ def grid_shard_main(a, world, rank):
         lat = one_step(s)
     torch.cuda.synchronize()
     local_ms = (time.perf_counter() - t0) * 1e3
+    barrier(world)
+    elapsed = time.perf_counter() - t0               # the timed region ends HERE; what follows is measured on the side
     if a.shard_path == "native":
         tot = filler.totals(reset=True)             # running totals kept on the device by the fills: one read, after the clock
         fwd_pts[0] = float(sum(tot["fwd_per_level"]))
@@ -896,8 +898,6 @@ def grid_shard_main(a, world, rank):
             filler.fill_grid(ShardedField(make_udf_func(dec, lat[k], sample=k)), 2 ** 22, out=(udf, grads), stats=False)
     torch.cuda.synchronize()
     shard_ms = (time.perf_counter() - t1) * 1e3 / B
-    barrier(world)
-    elapsed = time.perf_counter() - t0
     per_rank = None
     if world > 1:
         import torch.distributed as dist
