@@ -36,3 +36,18 @@ def unet_sd():
 def decoder_sd32():
     from surfd_amd.synth import synth_decoder_state_dict
     return synth_decoder_state_dict()
+
+
+def spawn_bounded(fn, args, nprocs, timeout_s=900):
+    """torch.multiprocessing.spawn with a deadline: a collective that never completes (a rank died, RCCL without peer access on
+    a new box) must fail the test, not hang the suite.  Only the processes started here are killed."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.start_processes(fn, args=args, nprocs=nprocs, join=False, start_method="spawn")
+    deadline = time.time() + timeout_s
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                if proc.is_alive():
+                    proc.kill()
+            pytest.fail(f"{fn.__name__}: {nprocs} ranks did not finish within {timeout_s} s")

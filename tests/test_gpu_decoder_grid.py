@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from conftest import spawn_bounded
 
 from oracle import decoder as odec
 from oracle import gridfiller as ogrid
@@ -686,7 +687,7 @@ def test_sharded_field_two_gpus_native_decoder():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_two_gpu_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_bounded(_two_gpu_shard_worker, (2, port, out), 2)
     assert out[0][0] and out[0][1] and out[1][0] and out[1][1]
     assert torch.equal(out[0][2], out[1][2]) and out[0][3] == out[1][3] > 0
 
@@ -752,7 +753,7 @@ def _run_native_shard(backend):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_native_shard_worker, args=(2, port, out, backend), nprocs=2, join=True)
+    spawn_bounded(_native_shard_worker, (2, port, out, backend), 2)
     assert out[0][0] and out[0][1] and out[1][0] and out[1][1]
     assert torch.equal(out[0][2], out[1][2]) and out[0][3] == out[1][3] > 0
 

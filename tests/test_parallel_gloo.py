@@ -8,6 +8,7 @@ import socket
 import types
 
 import torch
+from conftest import spawn_bounded
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -109,7 +110,7 @@ def test_sharded_equals_single_process():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_bounded(_worker, (2, port, out), 2)
     assert (out[0][1], out[0][2]) == (0, 2) and (out[1][1], out[1][2]) == (2, 1)
     for r in (0, 1):
         assert out[r][0].shape == (TOTAL, 1, L)
