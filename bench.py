@@ -105,7 +105,7 @@ def parse():
                     help="grid-shard: native = surfd_grid_shard_* (voxel-ordered lists, tiles r, r + G, ... of every level, fixed-capacity buffers summed "
                          "over the ranks, no host read between levels); callback = round 3's ShardedField over the host-callback grid API")
     ap.add_argument("--shard-capacity", type=int, default=0,
-                    help="grid-shard native: points a level's exchange buffer holds (0 = sized from the untimed shapes of the first step: 2 x their largest level — 4 x for gradient points — as a power of two, at least 2^22 / 2^21)")
+                    help="grid-shard native: points EVERY level's exchange buffer holds (0 = per level, from the untimed shapes of the first step: 2 x the largest count seen at that level — 4 x for gradient points — in whole tiles of every rank, at least 2^16)")
     ap.add_argument("--shard-grad-capacity", type=int, default=0, help="grid-shard native: gradient points the exchange buffer holds (0 = sized the same way)")
     ap.add_argument("--batch-grids", type=int, default=1,
                     help="1: the grids of a step are refined together, one decoder launch per level for all shapes "
@@ -839,26 +839,34 @@ def grid_shard_main(a, world, rank):
         return lat
 
     if a.shard_path == "native" and (a.shard_capacity <= 0 or a.shard_grad_capacity <= 0):
-        # exchange-buffer capacities from the field itself: one untimed shape with generous buffers, its device-side counts read
-        # once; every rank sees the same grid, hence the same counts and the same capacities (the collectives' sizes must agree)
+        # exchange-buffer capacities from the field itself, PER LEVEL: the B untimed shapes of the first step with generous
+        # buffers, their device-side counts read once each; every rank sees the same grids, hence the same counts and the same
+        # capacities (the collectives' sizes must agree).  Fields differ from shape to shape: twice the largest count seen per
+        # level (four times for the near-surface gradient points, which vary most), in whole tiles of every rank, at least 2^16
+        # — a thin-shell level travels as a few MB, not as the 64 MB of one global capacity.
         lat0 = diffusion.p_sample_loop(model, (B, 1, a.latent), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise_bank[0], fused=True)
         dec.bind_latents(lat0.reshape(B, a.latent))
-        top_f = top_g = 0
-        for k in range(B):          # the B shapes of the first step: fields differ, the capacities take the largest with a factor 2
+        seen = []
+        for k in range(B):
             filler.fill_grid_sharded(make_udf_func(dec, lat0[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=True,
                                      capacity=min(1 << 26, 7 * (N // 2) ** 3), grad_capacity=min(1 << 25, N ** 3))
-            top_f, top_g = max(top_f, max(filler.last_stats["fwd_per_level"])), max(top_g, filler.last_stats["grad"])
-        pow2 = lambda v, floor: 1 << max(floor, int(v - 1).bit_length())
-        if a.shard_capacity <= 0:
-            a.shard_capacity = pow2(2 * top_f, 22)
-        if a.shard_grad_capacity <= 0:
-            a.shard_grad_capacity = pow2(4 * top_g, 21)         # the near-surface count varies most from shape to shape
+            seen.append(filler.last_stats)
+        caps, gcap = filler.plan_shard_capacities(seen, world, margin=2.0, grad_margin=4.0)
+        if a.shard_capacity > 0:
+            caps = filler.shard_capacities(a.shard_capacity, gcap)[0]
+        if a.shard_grad_capacity > 0:
+            gcap = filler.shard_capacities(caps, a.shard_grad_capacity)[1]
+        a.shard_capacity, a.shard_grad_capacity = caps, gcap
         filler._shard_buf = None
         torch.cuda.empty_cache()
+    shard_caps = filler.shard_capacities(a.shard_capacity, a.shard_grad_capacity) if a.shard_path == "native" else None
     for s in range(a.warmup):
         one_step(s)
     if filler._handle is not None:
         filler.totals(reset=True)
+        if a.shard_path == "native":
+            filler.shard_overflows(reset=True)
+    filler.shard_bytes_exchanged = 0
     fwd_pts[0] = 0.0
     barrier(world)
     t0 = time.perf_counter()
@@ -871,11 +879,14 @@ def grid_shard_main(a, world, rank):
     if a.shard_path == "native":
         tot = filler.totals(reset=True)             # running totals kept on the device by the fills: one read, after the clock
         fwd_pts[0] = float(sum(tot["fwd_per_level"]))
-        # capacity check, once, on the last shape's counts (a cut level would have changed the totals of every shape alike)
-        st_last = filler._stats()
-        caps = [min(a.shard_capacity, 32 ** 3 if l == 0 else 7 * filler.N_levels[l - 1] ** 3) for l in range(len(filler.N_levels))]
-        assert all(c <= cap for c, cap in zip(st_last["fwd_per_level"], caps)) and st_last["grad"] <= min(a.shard_grad_capacity, N ** 3), \
-            f"--shard-capacity {a.shard_capacity} / --shard-grad-capacity {a.shard_grad_capacity} is too small for this field: {st_last}"
+        # capacity check over EVERY shape of the timed region: each commit compared its list with its buffer on the device
+        # (counts differ from shape to shape — the last shape's counts say nothing about the others); one read, after the clock
+        cut = filler.shard_overflows(reset=True)
+        assert cut == 0, (f"{cut} exchange buffer(s) of the timed region were shorter than their list (capacities {shard_caps}): the grids "
+                          f"of this run are incomplete — raise --shard-capacity / --shard-grad-capacity")
+    # what one shape hands to the collective (every level's buffer + the gradient buffer; with one rank nothing is exchanged, the
+    # figure is what 2+ ranks would move per rank and shape); SURVEY.md §8e sized an all-gather at <= 5 MB per thin-shell level
+    bytes_exchanged_per_shape = (4 * sum(shard_caps[0]) + 12 * shard_caps[1]) if shard_caps else None
     # the same shapes through the fused single-rank fill, timed the same way: what the sharded path costs by construction
     fused_ms = None
     if rank == 0 or world > 1:
@@ -919,7 +930,9 @@ def grid_shard_main(a, world, rank):
                                   "by index range, values returned by ncclAllGather (end point E1)", "mode": "grid-shard", "baseline_config": a.config,
                       "shapes_per_step": B, "resolution": N, "diffusion_steps": T, "decoder_fwd_queries_per_shape": fwd_pts[0] / max(shapes, 1),
                       "shard_path": a.shard_path, "host_syncs_per_shape": 0 if a.shard_path == "native" else len(filler.N_levels) + 1,
-                      "exchange_capacity_points": {"per_level": a.shard_capacity, "gradients": a.shard_grad_capacity} if a.shard_path == "native" else None,
+                      "exchange_capacity_points": {"per_level": shard_caps[0], "gradients": shard_caps[1]} if a.shard_path == "native" else None,
+                      "exchange_bytes_per_shape": bytes_exchanged_per_shape if a.shard_path == "native" else None,
+                      "exchange_buffers_cut_in_timed_region": 0 if a.shard_path == "native" else None,
                       "parallelism": (f"grid-shard x{world}: rank r evaluates tiles r, r + {world}, ... of every level's voxel-ordered list; fixed-capacity value "
                                       "buffers summed over the ranks (ncclAllReduce over xGMI), 4 B per point per level + 12 B per gradient point")
                                      if a.shard_path == "native" else

@@ -32,6 +32,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from surfd_amd import meshproc, synth  # noqa: E402
+from surfd_amd.rangeguard import run_guarded  # noqa: E402
 from surfd_amd.cbndec import CbnDecoder, CoordsEncoder, make_udf_func  # noqa: E402
 from surfd_amd.mdm import ClassifierFreeSampleModel, create_model_and_diffusion, load_model_wo_clip  # noqa: E402
 from surfd_amd.meshudf import get_mesh_from_udf, get_watertight_mesh  # noqa: E402
@@ -67,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--image_path", default=None)
     ap.add_argument("--mask_path", default=None)
     ap.add_argument("--sketch_path", default=None)
+    ap.add_argument("--strict", action="store_true",
+                    help="raise instead of re-running a stage in exact fp32 when the split-fp16 kernels had to clamp an operand")
     return ap.parse_args(argv)
 
 
@@ -162,21 +165,37 @@ def run(a):
     decoder.load_state_dict(torch.load(a.ae_dir, map_location="cpu")["decoder"], strict=True)
     decoder = decoder.cuda().eval()
 
-    latents = diffusion.p_sample_loop(model, (a.num_samples, 1, latent), clip_denoised=False, model_kwargs={"y": y}, progress=False)
+    # Range guard (surfd_amd/rangeguard.py): the default split-fp16 kernels clamp at +-65504 and count it; the reference is
+    # exact fp32 (models/mdm.py:46).  A stage that clamped is run again in the exact-fp32 mode on the same random numbers.
+    strict = bool(getattr(a, "strict", False))
+    core = model.model if isinstance(model, ClassifierFreeSampleModel) else model
+    rng = (torch.get_rng_state(), torch.cuda.get_rng_state())
+
+    def reverse_loop():
+        torch.set_rng_state(rng[0]); torch.cuda.set_rng_state(rng[1])      # both attempts draw the same noise
+        return diffusion.p_sample_loop(model, (a.num_samples, 1, latent), clip_denoised=False, model_kwargs={"y": y}, progress=False)
+
+    latents, _ = run_guarded("reverse loop (denoiser)", reverse_loop, core.saturation_count, lambda: core.set_precision("fp32"), strict)
     decoder.bind_latents(latents.reshape(a.num_samples, latent))
     stem = (a.prompt or a.mode).replace(" ", "-").replace(".", "")[:100]
     written = []
     for k in range(a.num_samples):
         field = make_udf_func(decoder, latents[k], sample=k)
-        if a.watertight:
-            verts, faces = get_watertight_mesh(field, a.resolution, max_batch=2 ** 16)
-            verts, faces = meshproc.keep_components_with_at_least(verts, faces, 5000)
-        else:
+
+        def shape_mesh():
+            if a.watertight:
+                verts, faces = get_watertight_mesh(field, a.resolution, max_batch=2 ** 16)
+                return meshproc.keep_components_with_at_least(verts, faces, 5000)
             v, t = get_mesh_from_udf(field, coords_range=(-1, 1), max_dist=0.1, N=a.resolution, max_batch=2 ** 16, differentiable=False)
             verts, faces = v.cpu().numpy(), t.cpu().numpy()
             if postprocess_open_mesh(a.mode):
                 verts = meshproc.laplacian_smooth(verts, faces, steps=3)
                 verts, faces = meshproc.keep_components_with_at_least(verts, faces, 2500)
+            return verts, faces
+
+        # once the decoder has been switched to fp32 it stays there for the remaining shapes of the request
+        (verts, faces), _ = run_guarded(f"shape {k} (decoder grids)", shape_mesh, decoder.saturation_count,
+                                        lambda: decoder.set_precision("fp32"), strict)
         path = os.path.join(a.output_dir, f"{stem}_{k}.obj")
         meshproc.write_obj(path, verts, faces)
         written.append((path, len(verts), len(faces)))

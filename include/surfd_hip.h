@@ -260,7 +260,10 @@ int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_
  * with the native decoder: rank r evaluates the 64-point tiles r, r + world, ... of each level's VOXEL-ORDERED point list (the
  * same list on every rank) into vals[point number] and leaves the other entries untouched (zero them first).  All calls are
  * stream-ordered and none reads a count back: list lengths stay on the device, `capacity` (points) bounds what a level may hold —
- * compare surfd_grid_get_stats with it afterwards.  With world = 1 the result equals surfd_grid_fill bit for bit. */
+ * a list longer than its buffer is cut and COUNTED on the device (surfd_grid_shard_overflows; the counts themselves are in
+ * surfd_grid_get_stats).  The handle tracks the protocol: a call that names another level than the open fill is at, a commit
+ * without an evaluation, or a commit with another capacity than its evaluation returns SURFD_ERR_STATE.
+ * With world = 1 the result equals surfd_grid_fill bit for bit. */
 int surfd_grid_shard_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s);
 int surfd_grid_shard_level_eval(surfd_grid *g, surfd_decoder *d, int sample, int level, int rank, int world, float *vals,
                                 int64_t capacity, surfd_stream s);
@@ -268,6 +271,9 @@ int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, i
 int surfd_grid_shard_grad_eval(surfd_grid *g, surfd_decoder *d, int sample, int rank, int world, float *ngrads, int64_t capacity,
                                surfd_stream s);
 int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, surfd_stream s);
+/* Exchange buffers that were shorter than the list they carried, over the sharded fills since the last reset (levels and gradient
+ * lists; 0 = every grid of that span is complete).  Synchronises the stream (one 8-byte read).  No reference counterpart. */
+int surfd_grid_shard_overflows(surfd_grid *g, int64_t *n, int reset, surfd_stream s);
 
 /* ------------------------------------------------------------------------------------ */
 /* UDF marching cubes (host side, no device): udf_mc_lewiner / marching_cubes_udf        */

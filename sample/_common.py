@@ -57,6 +57,8 @@ def generate_args(argv=None) -> argparse.Namespace:
     g.add_argument("--bpe_path", default=None, help="CLIP's BPE vocabulary (text mode with --clip_path)")
     g.add_argument("--respacing", default="", help="e.g. ddim50 for a quick run")
     g.add_argument("--synthetic", action="store_true", help="synthetic checkpoints instead of --model_path / --ae_dir")
+    g.add_argument("--strict", action="store_true",
+                   help="raise instead of re-running a stage in exact fp32 when the split-fp16 kernels had to clamp an operand")
     a = p.parse_args(argv)
     if a.cond_mask_prob == 0:          # utils/parser_util.py:19-20: without it the guidance scale is forced back to 1
         a.guidance_param = 1

@@ -32,6 +32,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace surfd {
 
@@ -49,6 +50,8 @@ struct Seg2 {
     int blk, blkp, nblk;   // channels per K block (= staged chunk), padded to 16, number of blocks
     int k16_off;           // first k16 step of the segment
     int gs;                // channels per GroupNorm group
+    int log2P, gsm;        // thread <-> channel map of the staging: lane = group slot * 2^log2P + position, gsm channels per slot
+                           // (segments with GroupNorm: gsm = gs, 2^log2P = gs rounded up to a power of two; others: one slot of 64)
 };
 
 struct Conv2Args {
@@ -86,14 +89,149 @@ struct Conv2Args {
     long long *dbg;        // -DSURFD_C2_STAMPS builds: 16 phase stamps (100 MHz ticks) of workgroup 0
 };
 
-constexpr int C2_D = 2;    // ring stages; with 4 k16 steps per stage 16 x 1 KB fragments are in flight per wave (3 stages do not fit 256 VGPRs)
+#ifndef SURFD_C2_EPI_LATE
+#define SURFD_C2_EPI_LATE 1
+#endif
+#ifndef SURFD_C2_LAT_D
+#define SURFD_C2_LAT_D 2
+#endif
+#ifndef SURFD_C2_DEEP_D
+#define SURFD_C2_DEEP_D 3
+#endif
+// ring stages: 2 (with 4 k16 steps per stage 16 x 1 KB fragments in flight per wave).  With the epilogue operands requested after
+// the K loop the two-workgroups-per-CU forms have room for a third stage (232 instead of 200 registers): measured SLOWER in the
+// latency form (SURFD_C2_LAT_D=3: 1.385 against 1.352 ms per evaluation at 8 latents — a wave's k-part there is 10-11 k16 steps,
+// 8 of them are in flight with two stages, and the third stage's 8 loads sit in front of the wait for the operand); the wide
+// form's two-per-CU kernel (one wave = the whole K slice, 42 k16 steps per 224-channel three-tap block) runs SURFD_C2_DEEP_D
 #ifndef SURFD_C2_LEAN_WAVES
 #define SURFD_C2_LEAN_WAVES 3          // waves per SIMD (= workgroups per CU) the lean form is compiled for: 3 -> 168 VGPRs, no spills
 #endif
 constexpr int C2_PLANE_NT2 = 13056;    // two column tiles per wave: 96 positions x (128 + 8) halfs; 2 planes + flag = 52 240 B, three workgroups per CU
 constexpr int C2_PLANE_LEAN = 10112;   // halfs per fp16 plane of the slab in the lean form: 2 planes + flag = 40 464 B, four workgroups per CU
 
-__device__ __forceinline__ float silu2(float v) { return v * __frcp_rn(1.f + __expf(-v)); }
+// SiLU of the operand staging: x * 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp).  __frcp_rn is an IEEE
+// division on this target — v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: ten instructions per value, a
+// quarter of everything the staging executes (read back from the code object) — for half an ulp nobody downstream can see:
+// the value is split into two fp16 terms with 2^-22 relative error right after.
+#ifndef SURFD_C2_FAST_RCP
+#define SURFD_C2_FAST_RCP 1
+#endif
+__device__ __forceinline__ float silu2(float v) {
+#if SURFD_C2_FAST_RCP
+    return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+#else
+    return v * __frcp_rn(1.f + __expf(-v));
+#endif
+}
+
+// Kernel-argument prefetch.  Conv2Args is 6-7 cache lines of kernarg segment; with 106 SGPRs the compiler fetches it in
+// seven batches, each behind an s_waitcnt lgkmcnt(0) and each touching lines the scalar cache has not seen in this launch
+// (the segment was last read one graph replay = 553 MB of weight stream ago): seven dependent misses before the first
+// operand load can be issued.  One dword of every line requested by the first instructions of the wave turns them into one
+// miss and six hits.
+#ifndef SURFD_C2_KAPF
+#define SURFD_C2_KAPF 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void c2_kernarg_prefetch() {
+#if SURFD_C2_KAPF
+    static_assert(BYTES > 0x180 && BYTES <= 0x1c0, "kernel-argument prefetch covers seven 64-byte lines");
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    int d0, d1, d2, d3, d4, d5, d6;
+    // the wait is part of the statement: the destinations are dead when it ends (no compiler-assigned value can be hit by a late
+    // return), and it costs nothing — the compiler's own first batch would wait for the same miss two instructions later
+    asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
+                 "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) : "s"(ka));
+#endif
+}
+
+// Experiment, OFF (the macro is the record; profiles/r05_loop_experiments.md): split-K partial tiles read with sc1 loads instead
+// of plain loads behind the last arriver's agent-scope acquire (buffer_inv sc1).  An sc1 load bypasses this CU's L1 — but the
+// partial buffer is re-used by every launch, and a copy of the line from an EARLIER launch's reduction can still sit in this
+// XCD's L2: with two loops and the decoder in flight the sequential and the pipelined run of
+// test_batch_pipeline_matches_sequential stopped agreeing bit for bit.  It bought nothing measurable either (2 x 80 latents
+// 3.31 vs 3.35 ms per evaluation, latency form 1.421 vs 1.413).  The acquire stays.
+#ifndef SURFD_C2_SC1_REDUCE
+#define SURFD_C2_SC1_REDUCE 0
+#endif
+__device__ __forceinline__ f32x4 c2_load_partial(const float *p) {
+#if SURFD_C2_SC1_REDUCE
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 r;
+    r[0] = __uint_as_float((unsigned)a); r[1] = __uint_as_float((unsigned)(a >> 32));
+    r[2] = __uint_as_float((unsigned)b); r[3] = __uint_as_float((unsigned)(b >> 32));
+    return r;
+#else
+    return *reinterpret_cast<const f32x4 *>(p);
+#endif
+}
+
+// Experiment, OFF by default (profiles/r05_loop_experiments.md §3): GroupNorm statistics without LDS and without barriers
+// (-DSURFD_C2_GNW=1).  Correct against every golden fixture and 1-2 % faster in the wide form, but NOT bit-stable run to run:
+// with three workgroups per CU the launches of the 4-position level (seven samples per workgroup, split-K 3 / 7 / 8) change
+// the last bits of one sample's statistics in about one evaluation of three (the butterfly itself is exact and stable in
+// isolation — tools/ubench/slot_sum_test.hip — also next to LDS traffic; one workgroup per CU, two per CU, no split-K, the
+// 256-register kernel or a row-after-row order of the same arithmetic are all stable; the cause was not found).  A latent's
+// bits must not depend on timing, so round 4's form below stays the default.  The staging maps thread <-> channel so that
+// every GroupNorm group of a K block sits in ONE wave, in a slot of 2^log2P consecutive lanes (7 channels -> 8 lanes, 14 -> 16,
+// 21 / 28 -> 32, 42 / 56 -> 64; the unused lanes of a slot stage nothing).  A group's sums are then a butterfly over the slot's
+// lanes: DPP for 2, 4, 8 and 16 lanes, v_permlane16_swap / v_permlane32_swap for 32 and 64 — every lane of a slot ends with the same bits (each step adds
+// the same two numbers on both sides).  Round 4's form (thread = channel in tid order, per-(row, channel) means through an LDS
+// exchange area, an 8-lane combine per (row, group), the results through LDS again: two barriers, three where the exchange
+// area aliases the slab) is kept behind -DSURFD_C2_GNW=0.
+#ifndef SURFD_C2_GNW
+#define SURFD_C2_GNW 0
+#endif
+template <int CTRL>
+__device__ __forceinline__ float c2_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// N independent sums, step by step (the N chains of dependent DPP / bpermute operations overlap); x must be zero in the lanes
+// of a slot that hold no channel
+#if defined(SURFD_C2_GNW_NOPK)         // developer aid: every chain opaque to the vectoriser (no v_pk_add_f32 over two chains)
+#define C2_OPAQUE(v) asm volatile("" : "+v"(v))
+#else
+#define C2_OPAQUE(v) do { } while (0)
+#endif
+// x[lane] + x[lane ^ W] for W = 16 / 32 on the vector ALU (gfx950: v_permlane16_swap / v_permlane32_swap exchange the odd
+// 16-lane rows / the upper half of the first operand with the even rows / the lower half of the second: with both operands x
+// the two results hold, in every lane, the two partners' values) — no LDS pipe, no lgkmcnt
+template <int W>
+__device__ __forceinline__ float c2_swap_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    if constexpr (W == 16) { const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); return __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); return __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+}
+template <int N>
+__device__ __forceinline__ void c2_slot_sum(float (&x)[N], int log2P) {
+    if (log2P > 0) {         // quad_perm [1,0,3,2]: lane ^ 1
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0xB1>(x[i]); C2_OPAQUE(x[i]); }
+    }
+    if (log2P > 1) {         // quad_perm [2,3,0,1]: lane ^ 2
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x4E>(x[i]); C2_OPAQUE(x[i]); }
+    }
+    if (log2P > 2) {         // row_half_mirror: the other quad of the 8
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x141>(x[i]); C2_OPAQUE(x[i]); }
+    }
+    if (log2P > 3) {         // row_mirror: the other half of the 16
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x140>(x[i]); C2_OPAQUE(x[i]); }
+    }
+    if (log2P > 4) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<16>(x[i]); C2_OPAQUE(x[i]); }
+    }
+    if (log2P > 5) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<32>(x[i]); C2_OPAQUE(x[i]); }
+    }
+}
 
 __device__ __forceinline__ void lds_bar() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -123,7 +261,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     static_assert(!LEAN || (WT && VEC == 8 && !PREF), "lean form: wide decomposition, rows of <= 32 positions, no operand prefetch");
     static_assert(!NT2 || (LEAN && !LF), "two column tiles per wave: lean form only");
     constexpr int NCT = NT2 ? 2 : 1;      // column tiles a wave accumulates
-    constexpr int EXS = NT2 ? 128 : 256;  // row stride of the GroupNorm exchange arrays = threads that own a channel
+    [[maybe_unused]] constexpr int EXS = NT2 ? 128 : 256;  // row stride of the GroupNorm exchange arrays = threads that own a channel
     // the register / LDS diet of the lean form, also applied to 64-position rows in the wide form (16 float4 of operand per
     // thread: without it the kernel spills 77 registers at two workgroups per CU)
     constexpr bool SLIM = LEAN || (WT && VEC == 16);
@@ -134,14 +272,18 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     // ring stage in the lean form)
     constexpr bool ONE_ACC = NT2 || (LEAN && SURFD_C2_LEAN_U == 3);
     constexpr int C2_U = (LEAN && !NT2) ? SURFD_C2_LEAN_U : SLIM ? 2 : 4;    // k16 steps per ring stage
-    constexpr bool ALIAS = SLIM;          // GroupNorm exchange arrays inside the (not yet written) slab
+    constexpr int C2_D = (VEC == 8 && SURFD_C2_EPI_LATE && !LEAN && !LF) ? (WT ? SURFD_C2_DEEP_D : SURFD_C2_LAT_D) : 2;
+    [[maybe_unused]] constexpr bool ALIAS = SLIM;          // GroupNorm exchange arrays inside the (not yet written) slab
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     _Float16 *slab = reinterpret_cast<_Float16 *>(lds_raw);
+#if !SURFD_C2_GNW
     float *ex_mean = reinterpret_cast<float *>(lds_raw + (ALIAS ? 0 : A.off_ex));     // [VEC][256]
     float *ex_m2 = ex_mean + VEC * 256;                                 // [VEC][256]  (NT2: [16 rows][128 channels])
     float *gstat = ex_m2 + VEC * 256;                                   // [nb * groups][2]
+#endif
     float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag (lean form: the flag alone)
 
+    c2_kernarg_prefetch<(int)sizeof(Conv2Args)>();
     const int tid = threadIdx.x, lane = tid & 63;
     // provably wave-uniform: everything derived from it (k-part, column tile, iteration ranges, weight bases) stays in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,9 +342,23 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     const int KP = 1 << log2kp;
     const int ct = (WT || nct == 1) ? 0 : (wave & 1);
     const int kpart = WT ? 0 : (nct == 1) ? wave : (wave >> 1);
-    // staging ownership: thread <-> channel (NT2: thread <-> (channel, half of the batch rows))
-    const int cthr = NT2 ? (tid & 127) : tid;
-    const int rhalf = NT2 ? (tid >> 7) : 0;
+    // staging ownership: thread <-> channel (NT2: thread <-> (channel, half of the batch rows)); the channel of a thread is a
+    // function of the segment (chan_of below): wave wc owns the group slots [wc * slots, (wc + 1) * slots) of the K block
+    const int zthr = NT2 ? (tid & 127) : tid;          // identity index, used where any thread will do (zero fill of padded channels)
+    const int wc = NT2 ? (wave & 1) : wave;
+    const int rhalf = NT2 ? (wave >> 1) : 0;
+    auto chan_of = [&](int s, bool &ok) -> int {
+#if SURFD_C2_GNW
+        const int lp = A.seg[s].log2P, gsm = A.seg[s].gsm;
+        const int pos = lane & ((1 << lp) - 1);
+        const int c = ((wc << (6 - lp)) + (lane >> lp)) * gsm + pos;
+        ok = pos < gsm && c < A.seg[s].blk;
+        return c;
+#else
+        ok = zthr < A.seg[s].blk;          // thread = channel
+        return zthr;
+#endif
+    };
     int colb[NCT], coll[NCT];
 #pragma unroll
     for (int t = 0; t < NCT; ++t) {
@@ -276,7 +432,8 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         const int bi = ch - (s ? nblk0 : 0);
         const int lv = A.seg[s].log2Lin - 2;          // log2(float4 per row)
         const int Lin = A.seg[s].Lin;
-        const int cg = min(bi * A.seg[s].blk + cthr, A.seg[s].C - 1);
+        bool cok_;
+        const int cg = min(bi * A.seg[s].blk + min(chan_of(s, cok_), A.seg[s].blk - 1), A.seg[s].C - 1);
         const float *src = A.seg[s].x + (long)cg * Lin;
         const long bstride = A.seg[s].bstride;
         const int rowbase = rhalf * ((VEC * 4) >> A.seg[s].log2Lin);      // first batch row this thread stages (NT2: second half of the rows)
@@ -288,6 +445,10 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         ga = A.seg[s].gamma[cg]; be = A.seg[s].beta[cg];      // segments without GroupNorm point these at the bias vector
     };
 
+#if defined(SURFD_C2_DBG_CLEARLDS)     // developer aid: nothing a previous workgroup left in LDS can be read
+    for (int e = tid; e < (int)(2 * PLANE / 2); e += 256) reinterpret_cast<unsigned *>(lds_raw)[e] = 0u;
+    lds_bar();
+#endif
     int ch = kz;
     WS cur = make_ws(ch);
     f32x4 v[VEC];
@@ -302,7 +463,10 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     f32x4 pre_b[4], pre_e[NCT][4];
     float pre_r[NCT][16];
     const float *embp = A.emb;                        // never null: the host points unused operands at the bias vector
-    if (A.step_ptr) embp += (long)(*A.step_ptr) * A.emb_step_stride;   // scalar load, requested here, first used by request_epilogue
+    // scalar load, requested here, first used by request_epilogue.  Through the constant address space: behind the prefetch
+    // statement above the compiler no longer proves the counter unclobbered and would fetch it with a VECTOR load — whose
+    // s_waitcnt vmcnt(0) in front of the address arithmetic waits for every weight fragment requested so far
+    if (A.step_ptr) embp += (long)(*reinterpret_cast<const __attribute__((address_space(4))) int *>((unsigned long)A.step_ptr)) * A.emb_step_stride;
     // head of a fused loop: the loop record, the iteration and its coefficient row are requested now — behind the operand and
     // weight requests above — and first used in the epilogue
     LoopFuse lfv;
@@ -333,7 +497,11 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             }
         }
     };
-    if constexpr (!SLIM) request_epilogue();
+    // SURFD_C2_EPI_LATE (default): every form requests the epilogue operands after the K loop.  Requested here they put 24 more
+    // vector-memory instructions per lane in front of the wait for the operand (the wave is busy issuing for ~2.6 us while the
+    // operand is back after ~1.3); after the K loop their round trip hides behind the k-part reduction and the split-K hand-off
+    constexpr bool EPI_LATE = SLIM || SURFD_C2_EPI_LATE;
+    if constexpr (!EPI_LATE) request_epilogue();
     bool saturated = false;
     C2_STAMP(1);
 
@@ -345,11 +513,14 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             const int lv = A.seg[s].log2Lin - 2, vpr = 1 << lv;
             const int Lin = A.seg[s].Lin;
             const int blk = A.seg[s].blk, blkp = A.seg[s].blkp;
-            const int c = cthr, cg = bi * blk + c;
-            const bool cok = c < blk;
+            bool cok;
+            const int c = chan_of(s, cok);
             const int rowbase = rhalf * ((VEC * 4) >> A.seg[s].log2Lin);
             const int pad = A.seg[s].taps == 3 ? 1 : 0;
             const int ups = A.seg[s].ups, act = A.seg[s].act;
+#if defined(SURFD_C2_DBG_WAITALL)      // developer aid: every outstanding load has landed before the operand is touched
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
             if (A.seg[s].gn) {
                 const int gs = A.seg[s].gs;
                 // ---- GroupNorm statistics, two-pass, in registers first: per (batch row, channel) mean and M2 over the
@@ -384,6 +555,71 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     rm2[j] = m2;
                 }
                 tree(rm2);
+#if SURFD_C2_GNW
+                // ---- per (batch row, group), inside the wave: equal-size rows combine exactly (Chan et al.):
+                //      mean = avg(row means),  M2 = sum(row M2) + Lin * sum((row mean - mean)^2).  The butterfly runs once per
+                //      row (at the row's first float4 — a wave-uniform choice); the results then go down the same binary tree the
+                //      row sums came up, so no register is indexed dynamically.
+                const int lp = A.seg[s].log2P;
+                const float inv_gs = 1.f / (float)gs, inv_cnt = 1.f / (float)(gs * Lin), flin = (float)Lin;
+                float gmr[VEC], gscr[VEC];
+                // S = float4 per row (compile time per branch of the wave-uniform dispatch below): the VEC / S rows of this thread
+                // go through the two butterflies together — rows past the batch chunk (clamped re-reads of the last row) included,
+                // their results are never used — and every float4 of a row receives the row's result by static index
+#if defined(SURFD_C2_GNW_LIVEONLY)     // developer aid: rows past the batch chunk contribute zeros
+#define C2_ROW_LIVE(i) (rowbase + (i) < nb)
+#else
+#define C2_ROW_LIVE(i) true
+#endif
+                auto group_stats = [&](auto stride) {
+                    constexpr int S = decltype(stride)::value, NR = VEC / S;
+                    float a[NR], gm[NR];
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) a[i] = (cok && C2_ROW_LIVE(i)) ? rs[i * S] : 0.f;
+                    c2_slot_sum<NR>(a, lp);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        gm[i] = a[i] * inv_gs;
+                        const float d = rs[i * S] - gm[i];
+                        a[i] = (cok && C2_ROW_LIVE(i)) ? rm2[i * S] + flin * (d * d) : 0.f;
+                    }
+                    c2_slot_sum<NR>(a, lp);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        const float sc = ga * (1.f / sqrtf(a[i] * inv_cnt + 1e-5f));
+#pragma unroll
+                        for (int m = 0; m < S; ++m) { gmr[i * S + m] = gm[i]; gscr[i * S + m] = sc; }
+                    }
+                };
+#if defined(SURFD_C2_GNW_ROWWISE)      // developer aid: one row after the other, dead rows skipped (the first form of this code)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    gmr[j] = 0.f; gscr[j] = 0.f;
+                    if ((j & (vpr - 1)) == 0 && rowbase + (j >> lv) < nb) {
+                        float a1[1] = {cok ? rs[j] : 0.f};
+                        c2_slot_sum<1>(a1, lp);
+                        const float gm1 = a1[0] * inv_gs, d = rs[j] - gm1;
+                        a1[0] = cok ? rm2[j] + flin * (d * d) : 0.f;
+                        c2_slot_sum<1>(a1, lp);
+                        gmr[j] = gm1; gscr[j] = ga * (1.f / sqrtf(a1[0] * inv_cnt + 1e-5f));
+                    }
+                }
+#pragma unroll
+                for (int lev = LOG2VEC - 1; lev >= 0; --lev)
+                    if (lev < lv) {
+#pragma unroll
+                        for (int j = 0; j < VEC; j += 2 << lev) { gmr[j + (1 << lev)] = gmr[j]; gscr[j + (1 << lev)] = gscr[j]; }
+                    }
+#else
+                if (lv == 0) group_stats(std::integral_constant<int, 1>());
+                else if (lv == 1) group_stats(std::integral_constant<int, 2>());
+                else if (lv == 2) group_stats(std::integral_constant<int, 4>());
+                else if (lv == 3 || VEC == 8) group_stats(std::integral_constant<int, 8>());
+                else group_stats(std::integral_constant<int, VEC>());
+#endif
+                C2_STAMP_FIRST(2);
+                C2_STAMP_FIRST(3);
+#else
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
                     if ((j & (vpr - 1)) == 0 && rowbase + (j >> lv) < nb) {     // first float4 of a live row (uniform per wave)
@@ -428,7 +664,10 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                         gmr[j] = gstat[2 * q]; gscr[j] = ga * gstat[2 * q + 1];
                     }
                 }
+#endif
+#if !SURFD_C2_GNW
                 if constexpr (ALIAS) lds_bar();
+#endif
                 if (cok) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
@@ -476,11 +715,12 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     }
                 }
                 saturated |= amax > 65504.f;
-            } else if (c < blkp) {                 // channels that only exist as padding of the K block: zeros
-                for (int i = 0; i < nb; ++i)
-                    for (int p = pad; p < pad + Lcov; ++p) { slab[(i * A.Lsl + p) * cs + c] = (_Float16)0.f; slab[(i * A.Lsl + p) * cs + c + PLANE] = (_Float16)0.f; }
             }
-            if (c < blkp)
+            if (zthr >= blk && zthr < blkp) {      // channels that only exist as padding of the K block: zeros (any thread will do)
+                for (int i = 0; i < nb; ++i)
+                    for (int p = 0; p < A.Lsl; ++p) { slab[(i * A.Lsl + p) * cs + zthr] = (_Float16)0.f; slab[(i * A.Lsl + p) * cs + zthr + PLANE] = (_Float16)0.f; }
+            }
+            if (cok)                               // halo positions of the channel this thread owns
                 for (int i = 0; i < nb; ++i) {
                     _Float16 *row0 = slab + (i * A.Lsl) * cs + c;
                     for (int p = 0; p < pad; ++p) { row0[p * cs] = (_Float16)0.f; row0[p * cs + PLANE] = (_Float16)0.f; }
@@ -576,7 +816,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             issue_operand(ch, v, ga, be);
         }
     }
-    if constexpr (SLIM) request_epilogue();      // round trip hidden behind the split-K hand-off (or the other workgroups of the CU)
+    if constexpr (EPI_LATE) request_epilogue();      // round trip hidden behind the split-K hand-off (or the other workgroups of the CU)
     if (saturated) atomicAdd(A.sat, 1u);
     C2_STAMP(6);
 
@@ -626,7 +866,9 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (prev == A.KS - 1) ? 1 : 0;
             if (last) {
+#if !SURFD_C2_SC1_REDUCE
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                 __hip_atomic_store(A.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             *flag = last;
@@ -644,7 +886,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                 for (int t = 0; t < NCT; ++t)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 pv = *reinterpret_cast<const f32x4 *>(src + ((size_t)((NT2 ? t : ct) * 4 + r4) * 64 + lane) * 4);
+                        const f32x4 pv = c2_load_partial(src + ((size_t)((NT2 ? t : ct) * 4 + r4) * 64 + lane) * 4);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) acc[t][4 * r4 + q] += pv[q];
                     }
@@ -696,6 +938,20 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         A.dbg[15] = (long long)__builtin_readcyclecounter() - cyc0_;       // shader cycles over the same span
     }
 #endif
+}
+
+// developer aid (SURFD_CONV_DEBUG=1 SURFD_CONV2_HASH=1): order-independent checksum of a launch's output into slot 0 of its
+// stamp record — run-to-run comparison of every layer without a host synchronisation between the launches
+__global__ void c2_hash_kernel(const float *p, long bstride, int B, int row, unsigned long long *out) {
+    unsigned long long h = 0ull;
+    const long n = (long)B * row;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long b = e / row, r = e - b * row;
+        h += (unsigned long long)__float_as_uint(p[b * bstride + r]) * (unsigned long long)(2 * e + 1);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -756,15 +1012,29 @@ static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; 
 
 // K blocking of one segment: a block is what one workgroup stages at a time (thread <-> channel, <= 256),
 // holds whole GroupNorm groups and is padded to a multiple of 16 channels in the packed K axis.
+// Group slots of the staging's thread <-> channel map (SURFD_C2_GNW): a GroupNorm group of gs channels takes 2^log2P >= gs
+// consecutive lanes of one wave, a wave holds 64 >> log2P slots, `waves` waves stage a K block.
+static int slot_log2(int gs) { int lp = 0; while ((1 << lp) < gs) ++lp; return lp; }
+static int max_groups_per_block(int gs, int waves) {
+#if SURFD_C2_GNW
+    if (gs > 64) return 0;
+    return waves * (64 >> slot_log2(gs));
+#else
+    (void)gs; (void)waves;
+    return 1 << 20;
+#endif
+}
+
 static bool seg_blocking(const SegPlan &sp, int &blk, int &blkp, int &nblk) {
     const int C = sp.C;
     if (sp.gn) {
         if (C % 32) return false;
         const int gs = C / 32;
         const int unit = gs * 8 / gcd_i(gs, 8);           // lcm(gs, 8)
-        if (unit > 256 || C % unit) return false;
+        const int gmax = max_groups_per_block(gs, 4);
+        if (unit > 256 || C % unit || unit / gs > gmax) return false;
         int m = 1;
-        while (unit * m * 2 <= 256 && (C / unit) % (m * 2) == 0) m *= 2;
+        while (unit * m * 2 <= 256 && (C / unit) % (m * 2) == 0 && unit * m * 2 / gs <= gmax) m *= 2;
         blk = unit * m;
     } else {
         blk = 0;
@@ -786,9 +1056,10 @@ static bool seg_blocking2(const SegPlan &sp, int &blk, int &blkp, int &nblk) {
     if (sp.gn) {
         if (C % 32) return false;
         const int gs = C / 32;
-        if (gs > 128) return false;
+        const int gmax = max_groups_per_block(gs, 2);
+        if (gs > 128 || gmax < 1) return false;
         int m = 32;
-        while (m > 1 && gs * m > 128) m >>= 1;
+        while (m > 1 && (gs * m > 128 || m > gmax)) m >>= 1;
         blk = gs * m;
     } else {
         for (int b = std::min(128, C); b >= 1; --b)
@@ -933,6 +1204,10 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         }
         S.blk = c.blk[s]; S.blkp = c.blkp[s]; S.nblk = c.nblk[s]; S.k16_off = c.k16_off[s];
         if (nt2) { S.blk = c.blk2[s]; S.blkp = c.blkp2[s]; S.nblk = c.nblk2[s]; S.k16_off = c.k16_off2[s]; }
+        S.log2P = 6; S.gsm = 64;                     // thread = channel
+#if SURFD_C2_GNW
+        if (sp.gn) { S.log2P = slot_log2(S.gs); S.gsm = S.gs; }      // one group per slot of 2^log2P lanes (seg_blocking: the block's groups fit its waves)
+#endif
         const int lsl = sp.taps == 3 ? (sp.stride == 2 ? 2 * A.Lout + 1 : A.Lout + 2) : A.Lout;
         max_lsl = std::max(max_lsl, lsl);
         max_blkp = std::max(max_blkp, S.blkp);
@@ -948,7 +1223,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     const bool fuse_head = io.lf && c.dst.buf == -3;                 // 80 workgroups, once per evaluation: keeps the 256-register form (no spills with the loop record live)
     // lean form (three workgroups per CU) wherever one batch entry's slab fits its 20 KB planes
     nt2 = nt2 && wt && VEC == 8 && lean_env;
-    const bool lean = nt2 || (wt && VEC == 8 && lean_env && !fuse_head && (size_t)A.Lsl * (max_blkp + 8) <= (size_t)C2_PLANE_LEAN);
+    bool lean = nt2 || (wt && VEC == 8 && lean_env && !fuse_head && (size_t)A.Lsl * (max_blkp + 8) <= (size_t)C2_PLANE_LEAN);
     const int nb_cap = nt2 ? std::max(1, 64 / A.Lout) : split ? 1 : std::min({(VEC * 4) / Lin0, std::max(1, (wt ? 32 : 64) / A.Lout), 8});
     int nb = std::min(B, nb_cap);
     // one fp16 plane of the slab has a fixed size (the kernel addresses the low plane with an immediate): 30 KB
@@ -967,7 +1242,11 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.off_ex = (int)lds;
     A.off_red = (int)lds;
     if (lean || (wt && VEC == 16)) lds += 16;      // the split-K flag; the GroupNorm exchange arrays alias the slab (2 x 8 (16) KB + 2 KB <= 2 planes)
+#if SURFD_C2_GNW
+    else lds += (size_t)(3 * 1024 + 4) * sizeof(float);       // k-part reduction scratch + flag (the GroupNorm statistics need no LDS)
+#else
     else lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
+#endif
     static const int lds_extra = env_int("SURFD_CONV2_LDS_EXTRA", 0);   // developer aid: fewer workgroups per CU (occupancy experiments)
     lds += (size_t)lds_extra;
     if (lds > 160 * 1024) return 1;
@@ -1016,6 +1295,25 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         if ((size_t)KS * base * A.part_stride > u->part_floats || base > 8192) KS = 1;
     }
     A.KS = KS;
+    // Deep form for launches that do not fill the lean form's slots anyway.  Decomposition, batch chunks and K split stay the
+    // lean form's (bits unchanged); what changes is the kernel: two workgroups per CU with 232 registers each instead of three
+    // with 168, i.e. a weight ring of SURFD_C2_DEEP_D x 4 k16 steps instead of 2 x 2.  A wave of the wide form runs its whole K
+    // slice against the ring, and with 4 steps in flight every step waits for a round trip (stamps: 214 ns per k16 step cold,
+    // 136 ns from a warm L2, against 40 ns of matrix time) — workgroups that have a CU to themselves gain nothing from slots
+    // they do not use.  SURFD_CONV2_DEEP_BELOW = workgroups per CU (x cu_budget) up to which a launch takes the deep kernel.
+    static const int deep_below = env_int("SURFD_CONV2_DEEP_BELOW", 0);
+    if (lean && !nt2 && deep_below > 0 && (long)A.nrt * KS * A.nby <= (long)deep_below * u->cu_budget) {
+        lean = false;
+        lds = (size_t)15360 * 2 * sizeof(_Float16);
+        lds = (lds + 15) & ~(size_t)15;
+        A.plane = 15360; A.off_ex = (int)lds; A.off_red = (int)lds;
+#if SURFD_C2_GNW
+        lds += (size_t)(3 * 1024 + 4) * sizeof(float);
+#else
+        lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
+#endif
+        lds += (size_t)lds_extra;
+    }
     A.part = u->part; A.counters = u->counters;
     A.sat = u->sat;
     if (fuse_head) {
@@ -1038,20 +1336,42 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     dim3 grid((unsigned)(G < 8 ? G * A.nby : 8 * ceil_div(G, 8) * A.nby));
     static const int pref = env_int("SURFD_CONV2_PREF", 0);      // operand prefetch across K blocks: measured 1.472 (on) vs 1.442 ms (off) per evaluation
     static const int wpref = env_int("SURFD_CONV2_WIDE_PREF", 0);
-    if (A.lf) {         // the head of a graph-replayed loop: same decompositions, posterior update in the epilogue
-        if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true, false, true>), grid, dim3(256), lds, st, A);
-        else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true, false, true>), grid, dim3(256), lds, st, A);
-        else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, false, false, true>), grid, dim3(256), lds, st, A);
-        else hipLaunchKernelGGL((conv2_kernel<8, false, false, false, true>), grid, dim3(256), lds, st, A);
+    auto launch = [&]() {
+        if (A.lf) {         // the head of a graph-replayed loop: same decompositions, posterior update in the epilogue
+            if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true, false, true>), grid, dim3(256), lds, st, A);
+            else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true, false, true>), grid, dim3(256), lds, st, A);
+            else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, false, false, true>), grid, dim3(256), lds, st, A);
+            else hipLaunchKernelGGL((conv2_kernel<8, false, false, false, true>), grid, dim3(256), lds, st, A);
+        }
+        else if (nt2) hipLaunchKernelGGL((conv2_kernel<8, false, true, true, false, true>), grid, dim3(256), lds, st, A);
+        else if (lean) hipLaunchKernelGGL((conv2_kernel<8, false, true, true>), grid, dim3(256), lds, st, A);
+        else if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true>), grid, dim3(256), lds, st, A);
+        else if (wt && wpref) hipLaunchKernelGGL((conv2_kernel<8, true, true>), grid, dim3(256), lds, st, A);
+        else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true>), grid, dim3(256), lds, st, A);
+        else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
+        else if (pref) hipLaunchKernelGGL((conv2_kernel<8, true>), grid, dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((conv2_kernel<8, false>), grid, dim3(256), lds, st, A);
+    };
+    launch();
+    LAUNCH_CHECK();
+    static const int hash_env = env_int("SURFD_CONV2_HASH", 0);
+    if (hash_env && A.dbg) {
+        HIP_TRY(hipMemsetAsync(A.dbg, 0, sizeof(long long), st));
+        hipLaunchKernelGGL(c2_hash_kernel, dim3(64), dim3(256), 0, st, (const float *)A.out, (long)A.out_bstride, B, A.Cout * A.Lout,
+                           reinterpret_cast<unsigned long long *>(A.dbg));
+        LAUNCH_CHECK();
     }
-    else if (nt2) hipLaunchKernelGGL((conv2_kernel<8, false, true, true, false, true>), grid, dim3(256), lds, st, A);
-    else if (lean) hipLaunchKernelGGL((conv2_kernel<8, false, true, true>), grid, dim3(256), lds, st, A);
-    else if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true>), grid, dim3(256), lds, st, A);
-    else if (wt && wpref) hipLaunchKernelGGL((conv2_kernel<8, true, true>), grid, dim3(256), lds, st, A);
-    else if (wt) hipLaunchKernelGGL((conv2_kernel<8, false, true>), grid, dim3(256), lds, st, A);
-    else if (VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false>), grid, dim3(256), lds, st, A);
-    else if (pref) hipLaunchKernelGGL((conv2_kernel<8, true>), grid, dim3(256), lds, st, A);
-    else hipLaunchKernelGGL((conv2_kernel<8, false>), grid, dim3(256), lds, st, A);
+    // developer aid (SURFD_CONV2_TWICE=1 with a -DSURFD_C2_STAMPS build): the same launch again, its stamps in the next slot — the
+    // second run finds the weights it streams in the L2s the first one left them in (cold vs warm weight stream, per layer)
+    static const int twice = env_int("SURFD_CONV2_TWICE", 0);
+    if (twice && !A.lf) {
+        if (A.dbg && u->dbg_launch < 4096) {
+            long long *prev = A.dbg;
+            A.dbg = u->dbg + (size_t)(u->dbg_launch++) * 16;
+            HIP_TRY(hipMemcpyAsync(A.dbg + 11, prev + 11, 4 * sizeof(long long), hipMemcpyDeviceToDevice, st));
+        }
+        launch();
+    }
     LAUNCH_CHECK();
     return SURFD_OK;
 }

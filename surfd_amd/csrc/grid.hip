@@ -248,6 +248,12 @@ __global__ void grad_commit_dev_kernel(const int *list, const int *count, long c
     }
 }
 
+// grid-shard mode: a list longer than the exchange buffer it travels in is cut (the buffers have a caller-chosen capacity, the
+// count lives on the device) — never silently: every commit compares and counts (surfd_grid_shard_overflows)
+__global__ void shard_overflow_kernel(const int *count, int per_entry, long cap, unsigned long long *overflow) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (long)per_entry * (long)*count > cap) *overflow += 1ull;
+}
+
 // counters of the fill that just finished -> running totals of the handle (device side, no host sync)
 __global__ void accumulate_totals_kernel(const int *counters, unsigned long long *totals, int n_levels, long level0, long dense_n) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -276,6 +282,12 @@ struct surfd_grid {
     unsigned long long *totals = nullptr;            // [MAX_LEVELS] forward queries per level, [MAX_LEVELS] gradient queries, [MAX_LEVELS + 1] fills — since the last reset
     void *sel_tmp = nullptr; size_t sel_tmp_bytes = 0;                                // fused path: ordered compaction of the gradient voxels
     unsigned char *flags[SURFD_GRID_MAX_LEVELS] = {};                                 // grid-shard mode: close flags per level lattice (allocated on first use)
+    // grid-shard protocol state: the level the next eval / commit must name (-1: no sharded fill open; n_levels: the gradient
+    // step), the capacity its eval calls used, whether the gradient list has been evaluated
+    int shard_level = -1;
+    int64_t shard_cap = 0;
+    bool shard_evaluated = false;
+    unsigned long long *overflow = nullptr;          // device: exchange buffers that were shorter than their list, since the last reset (grid-shard mode)
 };
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -351,6 +363,8 @@ static int grid_alloc(surfd_grid *g) {
     HIP_TRY(hipMemset(g->counters, 0, CTR_TOTAL * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&g->totals, (SURFD_GRID_MAX_LEVELS + 2) * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(g->totals, 0, (SURFD_GRID_MAX_LEVELS + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&g->overflow, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(g->overflow, 0, sizeof(unsigned long long)));
     g->allocated = true;
     return SURFD_OK;
 }
@@ -431,6 +445,7 @@ void surfd_grid_destroy(surfd_grid *g) {
     if (g->grad_list) (void)hipFree(g->grad_list);
     if (g->counters) (void)hipFree(g->counters);
     if (g->totals) (void)hipFree(g->totals);
+    if (g->overflow) (void)hipFree(g->overflow);
     if (g->sort_out) (void)hipFree(g->sort_out);
     if (g->sort_tmp) (void)hipFree(g->sort_tmp);
     if (g->sel_tmp) (void)hipFree(g->sel_tmp);
@@ -689,6 +704,7 @@ int surfd_grid_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s) {
     HIP_TRY(hipMemsetAsync(g->counters, 0, CTR_TOTAL * sizeof(int), st));
     if (grads) HIP_TRY(hipMemsetAsync(grads, 0, N3 * 3 * sizeof(float), st));
     g->cur_udf = udf; g->cur_grads = grads; g->dense_last = false;
+    g->shard_level = -1;
     return SURFD_OK;
 }
 
@@ -796,36 +812,62 @@ static int refine_level_ordered(surfd_grid *g, int level, float *udf, hipStream_
 }
 
 int surfd_grid_shard_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s) {
-    return surfd_grid_begin(g, udf, grads, s);
+    const int rc = surfd_grid_begin(g, udf, grads, s);
+    if (rc) return rc;
+    g->shard_level = 0; g->shard_cap = 0; g->shard_evaluated = false;
+    return SURFD_OK;
+}
+
+// The calls of one sharded fill come in a fixed order (every rank the same): level 0 eval (once per rank this process plays) ->
+// commit, level 1 ..., then the gradient pair.  Anything else would read stale parents, flags or counters: SURFD_ERR_STATE.
+static int shard_expect(surfd_grid *g, const char *fn, int level, int64_t capacity, bool commit) {
+    if (g->shard_level < 0) SURFD_FAIL(SURFD_ERR_STATE, "%s: call surfd_grid_shard_begin first", fn);
+    if (level != g->shard_level)
+        SURFD_FAIL(SURFD_ERR_STATE, "%s: out of order — the open fill is at %s %d, the call names %d", fn,
+                   g->shard_level >= g->n_levels ? "the gradient step after level" : "level", std::min(g->shard_level, g->n_levels - 1), level);
+    if (commit && !g->shard_evaluated) SURFD_FAIL(SURFD_ERR_STATE, "%s: nothing has been evaluated for this step yet", fn);
+    if (g->shard_evaluated && capacity != g->shard_cap)
+        SURFD_FAIL(SURFD_ERR_STATE, "%s: capacity %lld differs from the %lld the step's evaluation used", fn, (long long)capacity, (long long)g->shard_cap);
+    return SURFD_OK;
 }
 
 int surfd_grid_shard_level_eval(surfd_grid *g, surfd_decoder *d, int sample, int level, int rank, int world, float *vals,
                                 int64_t capacity, surfd_stream s) {
     int rc = check_ready(g, "surfd_grid_shard_level_eval");
     if (rc) return rc;
-    if (!g->cur_udf) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_level_eval: call surfd_grid_shard_begin first");
     if (level < 0 || level >= g->n_levels || !vals || capacity < 1 || world < 1 || rank < 0 || rank >= world)
         SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_eval: bad argument (level %d, rank %d of %d)", level, rank, world);
+    if ((rc = shard_expect(g, "surfd_grid_shard_level_eval", level, capacity, false))) return rc;
     PtIO io = eval_io(g, level);
+    if (level == 0 && io.n > capacity)
+        SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_eval: level 0 has %ld lattice points, the buffer holds %lld", io.n, (long long)capacity);
     io.out_udf = vals; io.cap = capacity; io.shard_n = world; io.shard_i = rank;
     const long hint = level == 0 ? ceil_div<long>(ceil_div<long>(std::min<long>(io.n, capacity), 64), world) : -1;
-    return decoder_launch(d, sample, io, false, hint, as_stream(s));
+    if ((rc = decoder_launch(d, sample, io, false, hint, as_stream(s)))) return rc;
+    g->shard_cap = capacity; g->shard_evaluated = true;
+    return SURFD_OK;
 }
 
 int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, int64_t capacity, surfd_stream s) {
     int rc = check_ready(g, "surfd_grid_shard_level_commit");
     if (rc) return rc;
-    if (!g->cur_udf) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_level_commit: call surfd_grid_shard_begin first");
     if (level < 0 || level >= g->n_levels || !vals || capacity < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_commit: bad argument");
+    if ((rc = shard_expect(g, "surfd_grid_shard_level_commit", level, capacity, true))) return rc;
     hipStream_t st = as_stream(s);
     PtIO io = eval_io(g, level);
     io.grid_udf = g->cur_udf; io.cap = capacity;
     const long upper = level == 0 ? io.n : capacity;
+    if (level > 0) {
+        hipLaunchKernelGGL(shard_overflow_kernel, dim3(1), dim3(64), 0, st, (const int *)(g->counters + CTR_PARENT + level), 7, (long)capacity, g->overflow);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(upper, 256), 4096)), dim3(256), 0, st, io, vals);
     LAUNCH_CHECK();
     if ((rc = refine_level_ordered(g, level, g->cur_udf, st))) return rc;
+    g->shard_level = level + 1; g->shard_evaluated = false; g->shard_cap = 0;
     if (level == g->n_levels - 1 && !g->cur_grads) {      // a fill without gradients ends here (otherwise surfd_grid_shard_grad_commit does this)
         g->dense_last = false;
+        g->shard_level = -1;
         return add_to_totals(g, 0, st);
     }
     return SURFD_OK;
@@ -837,12 +879,15 @@ int surfd_grid_shard_grad_eval(surfd_grid *g, surfd_decoder *d, int sample, int 
     if (rc) return rc;
     if (!g->cur_udf || !g->cur_grads) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_grad_eval: surfd_grid_shard_begin was not given a gradient buffer");
     if (!ngrads || capacity < 1 || world < 1 || rank < 0 || rank >= world) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_grad_eval: bad argument");
+    if ((rc = shard_expect(g, "surfd_grid_shard_grad_eval", g->n_levels, capacity, false))) return rc;
     hipStream_t st = as_stream(s);
-    if ((rc = compact_grad_list(g, g->cur_udf, g->grad_thr, st))) return rc;          // voxel order: the same list on every rank
+    if (!g->shard_evaluated && (rc = compact_grad_list(g, g->cur_udf, g->grad_thr, st))) return rc;          // voxel order: the same list on every rank
     PtIO io = base_io(g);
     io.mode = PT_LIST; io.list = g->grad_list; io.count_dev = g->counters + CTR_GRAD;
     io.out_ngrad = ngrads; io.cap = capacity; io.shard_n = world; io.shard_i = rank;
-    return decoder_launch(d, sample, io, true, -1, st);
+    if ((rc = decoder_launch(d, sample, io, true, -1, st))) return rc;
+    g->shard_cap = capacity; g->shard_evaluated = true;
+    return SURFD_OK;
 }
 
 int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, surfd_stream s) {
@@ -850,12 +895,30 @@ int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t cap
     if (rc) return rc;
     if (!g->cur_grads) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_grad_commit: no gradient buffer was given to surfd_grid_shard_begin");
     if (!ngrads || capacity < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_grad_commit: bad argument");
+    if ((rc = shard_expect(g, "surfd_grid_shard_grad_commit", g->n_levels, capacity, true))) return rc;
     hipStream_t st = as_stream(s);
+    hipLaunchKernelGGL(shard_overflow_kernel, dim3(1), dim3(64), 0, st, (const int *)(g->counters + CTR_GRAD), 1, (long)capacity, g->overflow);
+    LAUNCH_CHECK();
     hipLaunchKernelGGL(grad_commit_dev_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(capacity, 256), 4096)), dim3(256), 0, st,
                        (const int *)g->grad_list, (const int *)(g->counters + CTR_GRAD), (long)capacity, ngrads, g->cur_grads);
     LAUNCH_CHECK();
     g->dense_last = false;
+    g->shard_level = -1;
     return add_to_totals(g, 0, st);
+}
+
+// Exchange buffers that were shorter than the list they carried (levels and gradient lists, summed over the sharded fills since
+// the last reset): non-zero = at least one grid of that span is incomplete.  One 8-byte read; the counts behind it are in
+// surfd_grid_get_stats of the fill in question.
+int surfd_grid_shard_overflows(surfd_grid *g, int64_t *n, int reset, surfd_stream s) {
+    if (!g || !n) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_overflows: null argument");
+    if (!g->allocated) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_overflows: nothing has been filled yet");
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, g->overflow, sizeof(v), hipMemcpyDeviceToHost, as_stream(s)));
+    if (reset) HIP_TRY(hipMemsetAsync(g->overflow, 0, sizeof(v), as_stream(s)));
+    HIP_TRY(hipStreamSynchronize(as_stream(s)));
+    *n = (int64_t)v;
+    return SURFD_OK;
 }
 
 }  // extern "C"

@@ -1176,7 +1176,9 @@ int launch_conv(surfd_unet *u, const ConvPlan &c, int B, int L, const float *ext
                 const int ext_bmod[2], float *ext_out, long ext_out_bs, const float *emb, long emb_bs, hipStream_t st,
                 const int *step_ptr = nullptr, const LoopFuse *lf = nullptr, bool *lf_done = nullptr,
                 const float *lin_add = nullptr, long lin_add_step_stride = 0) {
-    if (u->precision == 1 && c.f16_ok && (u->dbg_only < 0 || u->dbg_only == c.id)) {
+    // dbg_only: -1 = every op; otherwise first | (last << 16): the ops [first, last] (last = 0: `first` alone) run on the f16x2 kernel
+    const int only_first = u->dbg_only & 0xffff, only_last = (u->dbg_only >> 16) ? (u->dbg_only >> 16) : only_first;
+    if (u->precision == 1 && c.f16_ok && (u->dbg_only < 0 || (c.id >= only_first && c.id <= only_last))) {
         const ConvLaunchIO io{ext_in[0], ext_in_bs[0], ext_out, ext_out_bs, emb, emb_bs, step_ptr, lf, lf_done};
         const int r2 = launch_conv2(u, c, B, L, io, st);
         if (r2 <= 0) return r2;          // launched (0) or failed (< 0); 1 = shape not covered -> fp32 kernel below

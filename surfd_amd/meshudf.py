@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Callable, Dict, Optional, Sequence, Tuple
+from typing import List,  Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -146,17 +146,68 @@ class GridFiller:
             self.last_stats = self._stats()
         return udf, grads
 
+    # ---- grid-shard mode -------------------------------------------------------------------------------------------------
+    SHARD_DEFAULT_CAPACITY = 1 << 24          # points per level: the synthetic decoder's 8 %-occupancy field at 512^3 has 13.0 M on its last level
+    SHARD_DEFAULT_GRAD_CAPACITY = 1 << 21     # gradient points (12 B each): 0.31 M for that field
+    SHARD_FLOOR = 1 << 16
+
+    def shard_capacities(self, capacity=None, grad_capacity=None) -> Tuple[List[int], int]:
+        """Per-level exchange capacities (points) and the gradient capacity for fill_grid_sharded: an int bounds every level, a
+        list names each level's own, None takes what plan_shard_capacities / the adaptive mode learned (the library defaults
+        before that).  A level never needs more than its lattice (level 0) or 7 children per cell of the previous one."""
+        nl = len(self.N_levels)
+        upper = [self.N_levels[0] ** 3] + [7 * self.N_levels[l - 1] ** 3 for l in range(1, nl)]
+        learned = getattr(self, "_shard_plan", None)
+        if capacity is None:
+            caps = list(learned[0]) if learned else [self.SHARD_DEFAULT_CAPACITY] * nl
+        elif isinstance(capacity, (list, tuple)):
+            if len(capacity) != nl:
+                raise ValueError(f"capacity lists one entry per level ({nl}), got {len(capacity)}")
+            caps = [int(c) for c in capacity]
+        else:
+            caps = [int(capacity)] * nl
+        if grad_capacity is None:
+            gcap = learned[1] if learned else self.SHARD_DEFAULT_GRAD_CAPACITY
+        else:
+            gcap = int(grad_capacity)
+        return [max(1, min(c, u)) for c, u in zip(caps, upper)], max(1, min(gcap, self.N_max ** 3))
+
+    def plan_shard_capacities(self, stats: Sequence[Dict], world: int = 1, margin: float = 1.5, grad_margin: float = 2.0) -> Tuple[List[int], int]:
+        """Exchange capacities from measured fills (`stats`: GridFiller.last_stats of one or more shapes — every rank holds the
+        same grids, hence the same counts, hence the same plan: the collectives' sizes agree by construction): per level
+        `margin` x the largest count seen, rounded up to whole 64-point tiles of every rank, at least 2^16 points.  A thin-shell
+        level then travels as a few MB instead of the 64 MB of the library default.  Remembered for capacity=None."""
+        nl = len(self.N_levels)
+        unit = 64 * max(1, world)
+        up = lambda v: ((int(math.ceil(v)) + unit - 1) // unit) * unit          # noqa: E731
+        caps = [up(max(self.SHARD_FLOOR, margin * max(st["fwd_per_level"][l] for st in stats))) for l in range(nl)]
+        gcap = up(max(self.SHARD_FLOOR, grad_margin * max(st["grad"] for st in stats)))
+        self._shard_plan = self.shard_capacities(caps, gcap)
+        return self._shard_plan
+
+    def shard_overflows(self, reset: bool = True) -> int:
+        """Exchange buffers that were shorter than the list they carried, over the sharded fills since the last reset (kept on the
+        device by the commits; one 8-byte read).  Non-zero: at least one grid of that span is incomplete."""
+        L, h = self._native()
+        n = C.c_int64()
+        N.check(L.surfd_grid_shard_overflows(h, C.byref(n), int(reset), N.stream()))
+        return int(n.value)
+
     def fill_grid_sharded(self, udf_func, rank: int = 0, world: int = 1, with_grads: bool = True,
-                          out: Optional[Tuple[Tensor, Optional[Tensor]]] = None, stats: bool = True, capacity: int = 1 << 24,
-                          grad_capacity: int = 1 << 21, exchange: Optional[Callable[[Tensor], None]] = None, simulate_ranks: bool = False):
+                          out: Optional[Tuple[Tensor, Optional[Tensor]]] = None, stats: bool = True, capacity=None,
+                          grad_capacity=None, exchange: Optional[Callable[[Tensor], None]] = None, simulate_ranks: bool = False,
+                          adaptive: bool = False):
         """Grid-shard mode, native: ONE shape's grid evaluated by `world` ranks.  Every rank calls this with the
         same latent; rank r runs the native decoder on the 64-point tiles r, r + world, ... of each level's voxel-ordered point
         list, `exchange(buffer)` sums the per-level value buffers over the ranks in place (default: torch.distributed
         all_reduce — ncclAllReduce over xGMI with backend "nccl"; world = 1: nothing), and every rank commits the whole level,
         derives the same next level and ends with the same grid.  Nothing is read back between levels: list lengths stay on the
-        device, the exchange buffers hold `capacity` points per level (`grad_capacity` gradient points: 12 B each) — checked against the
-        counts at the end when stats=True.  Defaults: 2^24 / 2^21, enough for the synthetic decoder's 8 %-occupancy field at 512^3 (13.0 M
-        points on its last level, 0.31 M gradient points); a trained model's thin shell needs a fifth of that.
+        device, a level's exchange buffer holds `capacity` points (an int, one per level as a list, or None = the learned plan /
+        the library default 2^24), the gradient buffer `grad_capacity` (12 B each; default 2^21).  A list longer than its buffer
+        is cut — and counted on the device (shard_overflows()); with stats=True the counts are read back and a cut raises.
+        adaptive=True (one read per shape): the capacities follow the field — every fill re-plans them from its own counts
+        (plan_shard_capacities) and a fill that was cut is repeated with buffers sized from what it needed; identical on every
+        rank because the counts are.  `self.shard_bytes_exchanged` sums the bytes handed to `exchange`.
         simulate_ranks=True (tests on one device): this process plays every rank in turn — the sharding logic without a second GPU.
         The result equals the fused single-rank fill bit for bit."""
         native = getattr(udf_func, "_surfd_native", None)
@@ -174,41 +225,55 @@ class GridFiller:
         else:
             udf, grads = out
         st = N.stream()
-        caps = [min(int(capacity), (self.N_levels[0] ** 3) if l == 0 else 7 * self.N_levels[l - 1] ** 3) for l in range(len(self.N_levels))]
-        gcap = min(int(grad_capacity), Nn ** 3)
-        need = max(max(caps), 3 * gcap if grads is not None else 0)
-        buf = getattr(self, "_shard_buf", None)
-        if buf is None or buf.numel() < need or buf.device != dev:
-            buf = self._shard_buf = torch.empty(need, device=dev, dtype=torch.float32)
         if exchange is None and world > 1 and not simulate_ranks:
             from .parallel import sum_over_ranks
             exchange = sum_over_ranks
         ranks = range(world) if simulate_ranks else (rank,)
-        N.check(L.surfd_grid_shard_begin(h, N.ptr(udf), N.ptr(grads), st))
-        for level, cap in enumerate(caps):
-            vals = buf[:cap]
-            if world > 1:
-                vals.zero_()
-            for r in ranks:
-                N.check(L.surfd_grid_shard_level_eval(h, dh, smp, level, r, world, N.ptr(vals), cap, st))
-            if exchange is not None:
-                exchange(vals)
-            N.check(L.surfd_grid_shard_level_commit(h, level, N.ptr(vals), cap, st))
-        if grads is not None:
-            ng = buf[:3 * gcap]
-            if world > 1:
-                ng.zero_()
-            for r in ranks:
-                N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, r, world, N.ptr(ng), gcap, st))
-            if exchange is not None:
-                exchange(ng)
-            N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(ng), gcap, st))
-        if stats:
+        if not hasattr(self, "shard_bytes_exchanged"):
+            self.shard_bytes_exchanged = 0
+        for attempt in range(3):
+            caps, gcap = self.shard_capacities(capacity, grad_capacity)
+            need = max(max(caps), 3 * gcap if grads is not None else 0)
+            buf = getattr(self, "_shard_buf", None)
+            if buf is None or buf.numel() < need or buf.device != dev:
+                buf = self._shard_buf = torch.empty(need, device=dev, dtype=torch.float32)
+            N.check(L.surfd_grid_shard_begin(h, N.ptr(udf), N.ptr(grads), st))
+            for level, cap in enumerate(caps):
+                vals = buf[:cap]
+                if world > 1:
+                    vals.zero_()                  # the sum over the ranks IS the exchange: entries of other ranks' tiles must be zero here
+                for r in ranks:
+                    N.check(L.surfd_grid_shard_level_eval(h, dh, smp, level, r, world, N.ptr(vals), cap, st))
+                if exchange is not None:
+                    exchange(vals)
+                    self.shard_bytes_exchanged += 4 * cap
+                N.check(L.surfd_grid_shard_level_commit(h, level, N.ptr(vals), cap, st))
+            if grads is not None:
+                ng = buf[:3 * gcap]
+                if world > 1:
+                    ng.zero_()
+                for r in ranks:
+                    N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, r, world, N.ptr(ng), gcap, st))
+                if exchange is not None:
+                    exchange(ng)
+                    self.shard_bytes_exchanged += 12 * gcap
+                N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(ng), gcap, st))
+            if not (stats or adaptive):
+                break
             self.last_stats = self._stats()
             over = [(l, c, cap) for l, (c, cap) in enumerate(zip(self.last_stats["fwd_per_level"], caps)) if c > cap]
-            if over or self.last_stats["grad"] > gcap:
-                raise RuntimeError(f"fill_grid_sharded: capacity {capacity} / grad_capacity {grad_capacity} points is too small for this field "
-                                   f"(levels over: {over}, gradient points {self.last_stats['grad']} of {gcap}): pass a larger capacity")
+            cut = bool(over) or (grads is not None and self.last_stats["grad"] > gcap)
+            if adaptive:
+                # a cut level hides how long its children would have been: plan from what was seen, with twice the margin, and go again
+                self.plan_shard_capacities([self.last_stats], world, margin=3.0 if cut else 1.5, grad_margin=4.0 if cut else 2.0)
+                if cut and attempt < 2:
+                    self.shard_overflows(reset=True)
+                    capacity = grad_capacity = None
+                    continue
+            if cut:
+                raise RuntimeError(f"fill_grid_sharded: exchange capacities {caps} / {gcap} gradient points are too small for this field "
+                                   f"(levels over: {over}, gradient points {self.last_stats['grad']} of {gcap}): pass larger ones, or adaptive=True")
+            break
         return udf, grads
 
     def fill_grid_dense(self, udf_func, max_dist: float = 0.1, with_grads: bool = True):

@@ -497,6 +497,28 @@ def test_decoder_saturation_is_counted():
         dec.set_precision("f16x2")
 
 
+def test_range_guard_reruns_a_clamping_stage_in_fp32(capsys):
+    """What the product drivers do with the saturation counters (surfd_amd/rangeguard.py, examples/generate.py): the lat = 200
+    decoder of the test above clamps in the f16x2 mode -> the guard re-runs the stage in exact fp32, says so once, and the
+    result is the fp32 kernel's; a clean stage is left alone; --strict raises.  Same for the denoiser's convs."""
+    from surfd_amd.rangeguard import RangeError, run_guarded
+    dec, _ = _decoder(32)
+    pts = (torch.rand(4096, 3, generator=torch.Generator().manual_seed(3)) * 2 - 1).cuda()
+    try:
+        dec.bind_latents((torch.randn(1, 32, generator=torch.Generator().manual_seed(4)) * 0.8).cuda())
+        u0, clamped = run_guarded("shape 0 (decoder grids)", lambda: dec.udf(pts, 0), dec.saturation_count, lambda: dec.set_precision("fp32"))
+        assert clamped == 0 and capsys.readouterr().err == ""
+        dec.bind_latents(torch.full((1, 32), 200.0).cuda())
+        with pytest.raises(RangeError):
+            run_guarded("shape 1 (decoder grids)", lambda: dec.udf(pts, 0), dec.saturation_count, lambda: dec.set_precision("fp32"), strict=True)
+        u1, clamped = run_guarded("shape 1 (decoder grids)", lambda: dec.udf(pts, 0), dec.saturation_count, lambda: dec.set_precision("fp32"))
+        err = capsys.readouterr().err
+        assert clamped > 0 and err.count("\n") == 1 and "shape 1 (decoder grids)" in err and "exact fp32" in err
+        assert torch.isfinite(u1).all() and torch.equal(u1, dec.udf(pts, 0)) and dec.saturation_count() == 0      # the handle is in fp32 now
+    finally:
+        dec.set_precision("f16x2")
+
+
 def test_callback_point_lists_are_in_voxel_order():
     """the device lists are appended with per-wave atomics (scheduling-dependent order); what the
     callback path hands to the host — and parallel.ShardedField splits over ranks by position — must be a

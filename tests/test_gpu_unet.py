@@ -416,6 +416,21 @@ def test_unet_saturation_is_counted():
         model.set_precision("f16x2")
 
 
+def test_range_guard_on_the_denoiser(capsys):
+    """surfd_amd.rangeguard with the denoiser's counter: an input beyond the fp16 range makes the first conv clamp; the guard
+    runs the evaluation again in the exact-fp32 mode and returns that result."""
+    from surfd_amd.rangeguard import run_guarded
+    model, _, _ = _model("no_cond")
+    x = torch.full((2, 1, 32), 1.0e6).cuda()
+    t = torch.tensor([5, 5]).cuda()
+    try:
+        out, clamped = run_guarded("reverse loop (denoiser)", lambda: model(x, t, y={}), model.saturation_count, lambda: model.set_precision("fp32"))
+        assert clamped > 0 and "reverse loop (denoiser)" in capsys.readouterr().err
+        assert torch.isfinite(out).all() and torch.equal(out, model(x, t, y={})) and model.saturation_count() == 0
+    finally:
+        model.set_precision("f16x2")
+
+
 def test_cached_loop_graph_survives_workspace_growth():
     """the cached loop graph bakes workspace / embedding-table pointers in; a larger-B call in
     between reallocates them.  The loop must re-capture, not replay against freed memory."""

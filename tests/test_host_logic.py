@@ -161,3 +161,64 @@ def test_phased_pipeline_plan_covers_every_batch_once():
                     seen.extend(range(f, f + cnt))
             assert seen == list(range(n)), (chains, mx, n)
     assert PhasedPipeline(None, None, chains=2, max_loop_batches=10).plan(20) == [(0, [(0, 0, 10), (1, 10, 10)])]      # the driver command: one round
+
+
+def test_range_guard_control_flow():
+    """surfd_amd.rangeguard.run_guarded (what examples/generate.py wraps the reverse loop and every shape's grids in): a clean
+    stage runs once; a stage whose saturation counter is non-zero is run again after the handle has been switched to exact
+    fp32, with one line logged; --strict raises instead; counts left behind by an earlier stage are not this stage's."""
+    from surfd_amd.rangeguard import RangeError, run_guarded
+
+    class Handle:
+        def __init__(self, clamps_in_f16x2, stale=0):
+            self.mode, self.pending, self.runs, self.clamps = "f16x2", stale, [], clamps_in_f16x2
+
+        def run(self):
+            self.runs.append(self.mode)
+            if self.mode == "f16x2":
+                self.pending += self.clamps
+            return f"result[{self.mode}]"
+
+        def read(self):                      # reads AND resets, like surfd_*_saturation_count(reset=1)
+            n, self.pending = self.pending, 0
+            return n
+
+        def to_fp32(self):
+            self.mode = "fp32"
+
+    lines = []
+    h = Handle(0, stale=7)                   # an earlier stage's count must not trigger a re-run
+    assert run_guarded("stage", h.run, h.read, h.to_fp32, log=lines.append) == ("result[f16x2]", 0)
+    assert h.runs == ["f16x2"] and lines == []
+    h = Handle(3)
+    out, clamped = run_guarded("shape 2 (decoder grids)", h.run, h.read, h.to_fp32, log=lines.append)
+    assert out == "result[fp32]" and clamped == 3 and h.runs == ["f16x2", "fp32"] and h.mode == "fp32"
+    assert len(lines) == 1 and "shape 2 (decoder grids)" in lines[0] and "3 workgroup" in lines[0] and "fp32" in lines[0]
+    out, clamped = run_guarded("shape 3", h.run, h.read, h.to_fp32, log=lines.append)      # the handle stays in fp32: one run, silent
+    assert out == "result[fp32]" and clamped == 0 and len(lines) == 1
+    h = Handle(1)
+    with pytest.raises(RangeError, match="--strict"):
+        run_guarded("reverse loop", h.run, h.read, h.to_fp32, strict=True, log=lines.append)
+    assert h.runs == ["f16x2"] and h.mode == "f16x2"
+
+    class Broken(Handle):                    # a counter that fires in the exact mode is a library bug, not a range problem
+        def run(self):
+            self.runs.append(self.mode); self.pending += 1
+            return None
+    b = Broken(1)
+    with pytest.raises(RuntimeError, match="no range limit"):
+        run_guarded("stage", b.run, b.read, b.to_fp32, log=lines.append)
+
+
+def test_drivers_expose_the_strict_flag():
+    """Both front ends (examples/generate.py and the reference-flag command lines behind sample/_common.py) accept --strict."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("generate_for_flags", os.path.join(root, "examples", "generate.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.parse(["uncond", "--strict"]).strict is True and mod.parse(["uncond"]).strict is False
+    from sample import _common
+    assert _common.generate_args(["--model_path", "m.pt", "--strict"]).strict is True
+    assert _common.generate_args(["--model_path", "m.pt"]).strict is False
