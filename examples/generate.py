@@ -173,7 +173,7 @@ def run(a):
 
     def reverse_loop():
         torch.set_rng_state(rng[0]); torch.cuda.set_rng_state(rng[1])      # both attempts draw the same noise
-        return diffusion.p_sample_loop(model, (a.num_samples, 1, latent), clip_denoised=False, model_kwargs={"y": y}, progress=False)
+        return diffusion.p_sample_loop(model, (a.num_samples, 1, latent), clip_denoised=False, model_kwargs={"y": y}, progress=True)   # as sample/generate_*.py
 
     latents, _ = run_guarded("reverse loop (denoiser)", reverse_loop, core.saturation_count, lambda: core.set_precision("fp32"), strict)
     decoder.bind_latents(latents.reshape(a.num_samples, latent))

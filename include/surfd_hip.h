@@ -109,6 +109,11 @@ int surfd_unet_set_wide(surfd_unet *u, int design_batch);
 /* host-sync: number of workgroups of the f16x2 conv kernel that had to clamp an operand to the fp16 range since the
  * last reset (0 = every evaluation so far was inside the range the mode is exact for) */
 int surfd_unet_saturation_count(surfd_unet *u, int reset, int64_t *count, surfd_stream s);
+/* Iterations the handle's fused reverse loop (surfd_sample_loop) has finished so far — the device-side loop counter, read over a
+ * private stream beside the one the loop runs on, so a host thread can draw the reference's progress bar
+ * (diffusion/gaussian_diffusion.py:677-681, `progress=True` in every sample/generate_*.py) while the loop is in flight.
+ * *iteration = -1 before the first loop. */
+int surfd_unet_loop_progress(surfd_unet *u, int *iteration);
 /* developer aid: op >= 0 restricts the f16x2 kernel to that one conv op of the plan (the others run fp32); -1 lifts it */
 int surfd_unet_debug_only_op(surfd_unet *u, int op);
 /* test tap: runs only the ops of ONE module of UNetModel ("input_blocks.1.0" ResBlock, "input_blocks.1.1" AttentionBlock,

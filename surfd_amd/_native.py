@@ -56,6 +56,7 @@ _SIGS = {
     "surfd_unet_set_cu_budget": (C.c_int, [_P, C.c_int]),
     "surfd_unet_set_wide": (C.c_int, [_P, C.c_int]),
     "surfd_unet_saturation_count": (C.c_int, [_P, C.c_int, c_i64p, _P]),
+    "surfd_unet_loop_progress": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "surfd_unet_debug_only_op": (C.c_int, [_P, C.c_int]),
     "surfd_unet_debug_run_module": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "surfd_sample_loop": (C.c_int, [_P, C.POINTER(SamplerCfg), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),

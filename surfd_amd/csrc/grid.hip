@@ -840,7 +840,7 @@ int surfd_grid_shard_level_eval(surfd_grid *g, surfd_decoder *d, int sample, int
     if ((rc = shard_expect(g, "surfd_grid_shard_level_eval", level, capacity, false))) return rc;
     PtIO io = eval_io(g, level);
     if (level == 0 && io.n > capacity)
-        SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_eval: level 0 has %ld lattice points, the buffer holds %lld", io.n, (long long)capacity);
+        SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_eval: level 0 has %ld lattice points, the exchange buffer's capacity is %lld", io.n, (long long)capacity);
     io.out_udf = vals; io.cap = capacity; io.shard_n = world; io.shard_i = rank;
     const long hint = level == 0 ? ceil_div<long>(ceil_div<long>(std::min<long>(io.n, capacity), 64), world) : -1;
     if ((rc = decoder_launch(d, sample, io, false, hint, as_stream(s)))) return rc;

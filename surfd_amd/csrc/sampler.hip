@@ -132,7 +132,10 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     // conditioned: the time part per step and the sample part per sample, the 22 per-ResBlock rows inside the graph
     // (SURFD_EMB_TABLE=1 keeps round 3's [T' x B, 14112] table: A/B timing)
     static const bool table_env = getenv("SURFD_EMB_TABLE") && atoi(getenv("SURFD_EMB_TABLE")) == 1;
-    const bool ingraph = !shared && !table_env;
+    // a model with BOTH class labels and a context vector (no Surf-D configuration has one: category models carry labels, the
+    // sketch / text / image models a context) keeps the table: the reference adds ((time + label) + context)
+    // (models/openaimodel.py:725-735), the in-graph rows add time + (context + label) — the same sum in another rounding order
+    const bool ingraph = !shared && !table_env && !(ctx && cls);
     std::vector<int64_t> t_rows((size_t)T * (ingraph ? 1 : per_step));
     for (int k = 0; k < T; ++k)
         for (int b = 0; b < (ingraph ? 1 : per_step); ++b) t_rows[(size_t)k * (ingraph ? 1 : per_step) + b] = cfg->timestep_map[T - 1 - k];
@@ -211,6 +214,22 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
     for (int k = 0; k < T; ++k) HIP_TRY(hipGraphLaunch(ls->exec, st));
     HIP_TRY(hipMemcpyAsync(x_out, ls->x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     prof_end(PROF_LOOP, prof_ev, st);
+    return SURFD_OK;
+}
+
+// Iterations the fused loop of this handle has finished (the device-side counter the head convolution advances), read over a
+// private stream BESIDE the stream the loop runs on: a host thread can draw the reference's progress bar
+// (diffusion/gaussian_diffusion.py:677-681) while surfd_sample_loop's graph replays are in flight.  -1: no loop has run yet.
+int surfd_unet_loop_progress(surfd_unet *u, int *iteration) {
+    if (!u || !iteration) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_loop_progress: null argument");
+    LoopState *ls = unet_loop_state(u);
+    *iteration = -1;
+    if (!ls->step_ctr) return SURFD_OK;
+    if (!ls->poll_stream) HIP_TRY(hipStreamCreateWithFlags(&ls->poll_stream, hipStreamNonBlocking));
+    int v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, ls->step_ctr, sizeof(int), hipMemcpyDeviceToHost, ls->poll_stream));
+    HIP_TRY(hipStreamSynchronize(ls->poll_stream));
+    *iteration = v;
     return SURFD_OK;
 }
 

@@ -1050,7 +1050,7 @@ void surfd_unet_destroy(surfd_unet *u) {
     if (u->vecs) (void)hipFree(u->vecs);
     if (u->label_table) (void)hipFree(u->label_table);
     for (float *p : u->buf_ptr) if (p) (void)hipFree(p);
-    for (float *p : {u->temb, u->h1, u->emb, u->emb_table}) if (p) (void)hipFree(p);
+    for (float *p : {u->temb, u->h1, u->emb, u->emb_table, u->emb_ctx}) if (p) (void)hipFree(p);
     if (u->t_dev) (void)hipFree(u->t_dev);
     if (u->part) (void)hipFree(u->part);
     if (u->counters) (void)hipFree(u->counters);
@@ -1058,6 +1058,7 @@ void surfd_unet_destroy(surfd_unet *u) {
     if (u->loop.exec) (void)hipGraphExecDestroy(u->loop.exec);
     if (u->loop.graph) (void)hipGraphDestroy(u->loop.graph);
     if (u->loop.cap_stream) (void)hipStreamDestroy(u->loop.cap_stream);
+    if (u->loop.poll_stream) (void)hipStreamDestroy(u->loop.poll_stream);
     for (void *p : {(void *)u->loop.step_ctr, (void *)u->loop.x, (void *)u->loop.x0, u->loop.params, (void *)u->loop.tab}) if (p) (void)hipFree(p);
     delete u;
 }

@@ -69,6 +69,7 @@ struct LoopState {
     hipGraphExec_t exec = nullptr;  // cached instantiated step graph
     hipGraph_t graph = nullptr;
     hipStream_t cap_stream = nullptr;   // private stream used only to record the graph (the caller's may be the null stream)
+    hipStream_t poll_stream = nullptr;  // surfd_unet_loop_progress: reads the loop counter beside the stream the loop runs on
     long key[6] = {0, 0, 0, 0, 0, 0};
 };
 LoopState *unet_loop_state(surfd_unet *u);

@@ -231,8 +231,41 @@ class SpacedDiffusion:
             y = (model_kwargs or {}).get("y", {})
             _ = y["scale"].view(-1, 1, 1)          # KeyError / AttributeError exactly where the reference would fail
 
+    @staticmethod
+    def _progress_bar(mdm, T):
+        """progress=True for the fused loop (every sample/generate_*.py of the reference passes it, gaussian_diffusion.py:677-681):
+        the loop is ONE C call, so the bar is drawn by a thread that polls the device-side loop counter
+        (surfd_unet_loop_progress) while the graph replays are in flight.  -> (stop, thread)"""
+        import threading
+        from tqdm.auto import tqdm
+        Lh, h = mdm._native()
+        stop = threading.Event()
+
+        def draw():
+            bar = tqdm(total=T)
+            it = C.c_int(-1)
+            seen_reset = False            # the counter of a previous loop (= its T) is still there until this loop's memset runs
+            while True:
+                done = stop.is_set()
+                N.check(Lh.surfd_unet_loop_progress(h, C.byref(it)))
+                v = int(it.value)
+                if v < T:
+                    seen_reset = True
+                if done:
+                    v = T
+                if (seen_reset or done) and v > bar.n:
+                    bar.update(min(v, T) - bar.n)
+                if done:
+                    break
+                time.sleep(0.02)
+            bar.close()
+
+        th_ = threading.Thread(target=draw, daemon=True)
+        th_.start()
+        return stop, th_
+
     def _fused_loop(self, mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device,
-                    return_trajectory=False):
+                    return_trajectory=False, progress=False):
         B, L = shape[0], shape[-1]
         T = self.num_timesteps
         if noise_stream is None:
@@ -258,10 +291,21 @@ class SpacedDiffusion:
         out = th.empty(B, *shape[1:], device=device, dtype=th.float32)
         traj = th.empty(T, B, *shape[1:], device=device, dtype=th.float32) if return_trajectory else None
         Lh, h = mdm._native()
+        bar = self._progress_bar(mdm, T) if progress else None
         t0 = time.time()
-        N.check(Lh.surfd_sample_loop(h, C.byref(cfg), N.ptr(noise_stream), N.ptr(ctx), N.ptr(cls), N.ptr(out), N.ptr(traj),
-                                     B, L, N.stream()))
-        self.time_con.append(time.time() - t0)
+        try:
+            N.check(Lh.surfd_sample_loop(h, C.byref(cfg), N.ptr(noise_stream), N.ptr(ctx), N.ptr(cls), N.ptr(out), N.ptr(traj),
+                                         B, L, N.stream()))
+            if bar is not None:
+                th.cuda.current_stream(device).synchronize()       # the bar ends when the loop has (the reference's loop is synchronous)
+        finally:
+            if bar is not None:
+                bar[0].set(); bar[1].join()
+        # one entry per step, like the reference's per-iteration bookkeeping (gaussian_diffusion.py:683, 708): the loop's host-side
+        # time shared evenly (its iterations are replays of one graph); without progress=True the call returns when the replays
+        # are queued, not when they have run
+        dt = (time.time() - t0) / T
+        self.time_con.extend([dt] * T)
         return (out, traj) if return_trajectory else out
 
     def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
@@ -338,7 +382,7 @@ class SpacedDiffusion:
             self._check_cfg_contract(model, model_kwargs)
             dev = device if device is not None else next(model.parameters()).device
             return self._fused_loop(mdm, tuple(shape), "ddpm", noise, noise_stream, clip_denoised, model_kwargs, 0.0, dev,
-                                    return_trajectory)
+                                    return_trajectory, progress=progress)
         final, dump = None, []
         for i, sample in enumerate(self.p_sample_loop_progressive(
                 model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
@@ -361,7 +405,7 @@ class SpacedDiffusion:
         if mdm is not None:
             self._check_cfg_contract(model, model_kwargs)
             dev = device if device is not None else next(model.parameters()).device
-            return self._fused_loop(mdm, tuple(shape), "ddim", noise, noise_stream, clip_denoised, model_kwargs, eta, dev)
+            return self._fused_loop(mdm, tuple(shape), "ddim", noise, noise_stream, clip_denoised, model_kwargs, eta, dev, progress=progress)
         final = None
         for sample in self.ddim_sample_loop_progressive(
                 model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,

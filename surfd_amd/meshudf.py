@@ -246,7 +246,8 @@ class GridFiller:
                     N.check(L.surfd_grid_shard_level_eval(h, dh, smp, level, r, world, N.ptr(vals), cap, st))
                 if exchange is not None:
                     exchange(vals)
-                    self.shard_bytes_exchanged += 4 * cap
+                if world > 1:
+                    self.shard_bytes_exchanged += 4 * cap          # what the collective moves per rank (also when one process plays the ranks)
                 N.check(L.surfd_grid_shard_level_commit(h, level, N.ptr(vals), cap, st))
             if grads is not None:
                 ng = buf[:3 * gcap]
@@ -256,6 +257,7 @@ class GridFiller:
                     N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, r, world, N.ptr(ng), gcap, st))
                 if exchange is not None:
                     exchange(ng)
+                if world > 1:
                     self.shard_bytes_exchanged += 12 * gcap
                 N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(ng), gcap, st))
             if not (stats or adaptive):

@@ -31,22 +31,27 @@ def _cos(a, b):
 
 
 def _check_directions(c, label=""):
-    """Stated tolerance on -normalize(grad udf): cosine >= 1 - 1e-5, asserted for >= 99.8 % of the
+    """Stated tolerance on -normalize(grad udf): cosine >= 1 - 1e-5, asserted for >= 99.9 % of the
     points — the measured level: the field is piecewise linear in 11 x 512 ReLU units, and a point whose
     pre-activation is within fp32 rounding of a kink takes the other branch in a different-but-equally-valid fp32
     evaluation order.  Measured on the reference itself (tools/make_golden.py g8flips -> tests/golden/g8_direction_flips.json):
     its own fp32 sample_grads against an fp64 copy of the same decoder disagrees (cos <= 1 - 1e-5) on 0.024 % of the G8
     points at D=32 (worst cosine 0.9935) and on none at D=64; this library against the reference's fp32 values: 0.06 %
-    observed.  The asserted bound (0.2 %) is ~3x the observed level.  Fraction and worst cosine are printed with every run."""
+    observed.  The asserted bound is 0.1 % (round 4: 0.2 %) — 4x the reference's own flip rate, under 2x the level observed
+    here — and the worst cosine must stay above 0.99 (the reference's own worst: 0.9935; round 4 asserted 0.9).  Fraction and
+    worst cosine are printed with every run."""
     c = np.asarray(c)
     if c.size == 0:
         return
     bad = int((c <= 1 - 1e-5).sum())
     print(f"directions{label}: n={c.size} cos>1-1e-5 on {100.0 * (1 - bad / c.size):.3f} % of points, "
           f"median 1-{1 - np.median(c):.1e}, worst cosine {c.min():.6f}")
-    assert bad <= max(1, int(np.ceil(0.002 * c.size))), (bad, c.size)
+    # 0.1 % of the points; samples of a few thousand points get the 3-sigma counting allowance of that rate on top (4 flips in
+    # 3 000 points have been seen: 0.13 % of a sample whose expectation at 0.05 % is 1.5)
+    allowed = np.ceil(0.001 * c.size) if c.size >= 20000 else np.ceil(0.001 * c.size + 3.0 * np.sqrt(0.001 * c.size))
+    assert bad <= max(1, int(allowed)), (bad, c.size)
     assert np.median(c) > 1 - 1e-6
-    assert c.min() > 0.9
+    assert c.min() > 0.99
 
 
 def test_library_and_device():
@@ -745,8 +750,74 @@ def test_native_sharded_fill_equals_fused_fill(world, precision):
             GridFiller(128).fill_grid_sharded(f, world=world, simulate_ranks=True, capacity=4096)
         with pytest.raises(RuntimeError, match="capacity"):
             GridFiller(128).fill_grid_sharded(f, world=world, simulate_ranks=True, grad_capacity=64)
+        # ... and COUNTED on the device when nobody reads the counts back (stats=False: the timed loops of bench.py): per-level
+        # capacities, the last level one tile short of what this field needs
+        counts = ref.last_stats["fwd_per_level"]
+        gc = GridFiller(128)
+        assert gc.fill_grid_sharded(f2, world=world, simulate_ranks=True, stats=False, capacity=[counts[0], 1 << 21, 1 << 21]) is not None
+        gc.fill_grid_sharded(f, world=world, simulate_ranks=True, stats=False, capacity=1 << 21)
+        assert gc.shard_overflows(reset=False) == 0
+        st2 = gc._stats()["fwd_per_level"]
+        gc.fill_grid_sharded(f, world=world, simulate_ranks=True, stats=False, capacity=[st2[0], st2[1], st2[2] - 64])
+        assert gc.shard_overflows() == 1 and gc.shard_overflows() == 0                   # read + reset
+        # adaptive capacities: every fill plans the next one's buffers from its own counts (a thin level travels as what it
+        # holds, not as 2^24 points); a plan that turns out too small is noticed and the fill repeated — same bits either way
+        ga = GridFiller(128)
+        u1, g1 = ga.fill_grid_sharded(f, world=world, simulate_ranks=True, adaptive=True)
+        caps, gcap = ga._shard_plan
+        assert torch.equal(u1, udf_1) and torch.equal(g1, grads_1)
+        assert all(cnt <= cap <= max(1 << 16, 2 * cnt + 64 * world) for cnt, cap in zip(ga.last_stats["fwd_per_level"][1:], caps[1:]))
+        u2, g2 = ga.fill_grid_sharded(f2, world=world, simulate_ranks=True, adaptive=True)
+        assert torch.equal(u2, a) and torch.equal(g2, b)
+        ga._shard_plan = ([caps[0], 1 << 16, 1 << 16], 1 << 16)                           # far too small for level 2 of this field
+        before = ga.shard_bytes_exchanged
+        u3, g3 = ga.fill_grid_sharded(f, world=world, simulate_ranks=True, adaptive=True)
+        assert torch.equal(u3, udf_1) and torch.equal(g3, grads_1) and ga.shard_overflows() == 0
+        assert (ga.shard_bytes_exchanged > before) == (world > 1)                          # bytes are counted where an exchange happens
     finally:
         dec.set_precision("f16x2")
+
+
+def test_grid_shard_protocol_state_is_checked():
+    """the surfd_grid_shard_* calls of one fill come in a fixed order; a call that names another level than the open
+    fill is at, a commit without an evaluation, a commit with another capacity than its evaluation, or anything before
+    shard_begin returns SURFD_ERR_STATE instead of reading stale parents / flags / counters."""
+    import ctypes as C
+    from surfd_amd import _native as N
+    from surfd_amd.cbndec import make_udf_func
+    from surfd_amd.meshudf import GridFiller
+    dec, _ = _decoder(32)
+    lat = (torch.randn(1, 32, generator=torch.Generator().manual_seed(23)) * 0.8).cuda()
+    f = make_udf_func(dec, lat)
+    gf = GridFiller(64)
+    gf.fill_grid(f, 2 ** 16)                                # allocates the handle's device state
+    L, h = gf._native()
+    _, dh = dec._native()
+    smp = dec._bind_single(lat)
+    st = N.stream()
+    udf = torch.empty(64, 64, 64, device="cuda"); grads = torch.empty(64, 64, 64, 3, device="cuda")
+    buf = torch.zeros(1 << 18, device="cuda")
+    ERR_STATE = -2
+    cap = 32 ** 3
+    assert L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st) == ERR_STATE          # nothing open
+    N.check(L.surfd_grid_shard_begin(h, N.ptr(udf), N.ptr(grads), st))
+    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st) == ERR_STATE                       # commit before eval
+    assert L.surfd_grid_shard_level_eval(h, dh, smp, 1, 0, 1, N.ptr(buf), 1 << 18, st) == ERR_STATE     # level 1 before level 0
+    assert L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), 1 << 16, st) == ERR_STATE         # gradients before the levels
+    N.check(L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st))
+    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap - 64, st) == ERR_STATE                  # another capacity than the eval
+    N.check(L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st))
+    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st) == ERR_STATE                       # level 0 is closed
+    N.check(L.surfd_grid_shard_level_eval(h, dh, smp, 1, 0, 1, N.ptr(buf), 1 << 18, st))
+    N.check(L.surfd_grid_shard_level_commit(h, 1, N.ptr(buf), 1 << 18, st))
+    assert L.surfd_grid_shard_grad_commit(h, N.ptr(buf), 1 << 16, st) == ERR_STATE                       # gradient commit before its eval
+    N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), 1 << 16, st))
+    N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(buf), 1 << 16, st))
+    assert L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st) == ERR_STATE          # the fill is closed
+    # what the protocol produced is the fused fill's grid
+    a, b = GridFiller(64).fill_grid(f, 2 ** 16)
+    torch.cuda.synchronize()
+    assert torch.equal(a, udf) and torch.equal(b, grads)
 
 
 def _native_shard_worker(rank, world, port, out, backend):

@@ -359,6 +359,54 @@ def test_c4_ddpm1000_text_cfg_end_to_end_vs_reference(golden):
     assert err <= 1e-4
 
 
+@pytest.mark.parametrize("design", [80])
+def test_wide_form_l64_text_cfg_chain_vs_reference(golden, design):
+    """The wide form's 64-position path (two 32-column halves per sample, VEC = 16 kernel) at the bench's design batch against the
+    reference's own 1000-step conditioned chain (G12 text + CFG, L = 64): until round 5 only L = 32 chains rode the wide golden
+    chain."""
+    from surfd_amd.mdm import ClassifierFreeSampleModel, create_model_and_diffusion, load_model_wo_clip
+    g = golden("g12_ddpm1000_contractive_textcfg_B2_L64")
+    model, diff = create_model_and_diffusion(_args("img"))
+    load_model_wo_clip(model, synth.synth_unet_state_dict(head_gain=float(g["head_gain"])))
+    model.to("cuda").eval()
+    model.cond_mode = "text"
+    model.set_wide(design)
+    B, L = 2, 64
+    w = ClassifierFreeSampleModel(model)
+    noise = synth.synth_noise_batch(1000, 0, B, L, seed=int(g["seed"])).cuda()
+    kw = {"y": {"context": synth.synth_context(0, B, seed=int(g["ctx_seed"])).cuda(),
+                "scale": torch.full((B,), float(g["scale"])).cuda()}}
+    out = diff.p_sample_loop(w, (B, 1, L), clip_denoised=False, model_kwargs=kw, noise_stream=noise, fused=True)
+    err = float(np.abs(out.cpu().numpy() - g["x_after_999"]).max())
+    print(f"wide form (design batch {design}), C4 1000-step end-to-end |x - reference| = {err:.2e}")
+    assert err <= 1e-4 and model.saturation_count() == 0
+
+
+def test_fused_loop_progress_bar_and_time_con(capsys):
+    """What every sample/generate_*.py of the reference relies on (gaussian_diffusion.py:677-708): progress=True draws a bar
+    over the T iterations, and time_con grows by one entry per iteration.  The fused loop is one C call: the bar is drawn from
+    the device-side loop counter (surfd_unet_loop_progress) while the replays are in flight; the result does not depend on it."""
+    model, _, _ = _model("no_cond")
+    _, dd, _ = _model("no_cond", "ddim50")
+    B, L, T_ = 2, 32, 50
+    noise = synth.synth_noise_batch(T_, 0, B, L).cuda()
+    n0 = len(dd.time_con)
+    quiet = dd.ddim_sample_loop(model, (B, 1, L), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise, fused=True, progress=False).clone()
+    assert len(dd.time_con) == n0 + T_
+    capsys.readouterr()
+    shown = dd.ddim_sample_loop(model, (B, 1, L), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise, fused=True, progress=True)
+    err = capsys.readouterr().err
+    assert torch.equal(shown, quiet)
+    assert len(dd.time_con) == n0 + 2 * T_ and all(v >= 0 for v in dd.time_con[n0:])
+    assert f"{T_}/{T_}" in err and "100%" in err, err[-300:]
+    from surfd_amd import _native as N
+    import ctypes as C
+    Lh, h = model._native()
+    it = C.c_int(-7)
+    N.check(Lh.surfd_unet_loop_progress(h, C.byref(it)))
+    assert it.value == T_                                   # the counter the bar read: every iteration of the last loop
+
+
 def test_unet_precision_modes_agree():
     """f16x2 (default) against the exact fp32 conv kernels on the same inputs: fp32-class agreement."""
     model, _, sd = _model("no_cond")
