@@ -55,6 +55,7 @@ FWD_FLOP = 5_308_416          # per forward decoder query
 UNET_WEIGHT_BYTES = 553_294_340   # 138 323 585 fp32 parameters streamed once per denoiser evaluation;
                                   # the f16x2 planes (two fp16 per weight) are the same number of bytes
 UNET_FLOP_PER_SAMPLE = {32: 2.057e9, 64: 4.104e9}
+MAX_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md: max shader clock; the matrix peaks are quoted at it
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TF = 2500.0     # MI355X dense fp16/bf16 matrix peak (same guide; not the 2:1-sparsity figure)
@@ -160,12 +161,56 @@ def self_launch(n_gpus):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+T_PROCESS_START = time.perf_counter()
+PINNED_CPUS = None          # this rank's CPU set once pin_rank_cpus has run (None: not pinned)
+
+
+def _cpu_ranges(cpus):
+    """[0, 1, 2, 3, 8, 9] -> '0-3,8-9'"""
+    cpus, out, i = sorted(cpus), [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def rank_cpu_slice(cpus, world, local):
+    """The CPUs rank `local` of `world` keeps: equal contiguous slices of the CPUs this process may run on (host logic, unit
+    tested).  Contiguous ids are neighbours in the topology on the hosts this runs on (cores of one socket / NUMA node are
+    numbered together), so a rank's loop threads, meshing threads and its share of torch's pool stay near each other and the
+    ranks never contend for a core.  Fewer than two CPUs per rank: no pinning."""
+    cpus = sorted(cpus)
+    per = len(cpus) // max(world, 1)
+    if world <= 1 or per < 2:
+        return None
+    return cpus[local * per:(local + 1) * per]
+
+
+def pin_rank_cpus(world, local):
+    """8 ranks x (2 loop threads + meshing threads + torch's intra-op pool) on one host: without placement the scheduler moves
+    them across sockets and the first thing that bends in a weak-scaling line is the host side.  SURFD_BENCH_NO_PIN=1
+    leaves the placement to the launcher."""
+    global PINNED_CPUS
+    if os.environ.get("SURFD_BENCH_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    mine = rank_cpu_slice(os.sched_getaffinity(0), world, local)
+    if mine:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+        PINNED_CPUS = mine
+    return mine
+
+
 def setup_dist(n_gpus):
     if n_gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(n_gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    pin_rank_cpus(world, local)
     # SURFD_BENCH_BACKEND=gloo: development aid — runs the N > 1 code path (launcher, barriers, per-rank gather) with
     # several ranks SHARING the GPUs that exist (RCCL refuses two ranks on one device); the number it prints is not a
     # scaling measurement and says so
@@ -450,7 +495,7 @@ class Job:
         self.mesher = None
         if endpoint == "e2":
             from surfd_amd.mcubes import BandMesher
-            threads = a.mesh_threads or max(1, min(8, (os.cpu_count() or 8) // world - n_chains))
+            threads = a.mesh_threads or max(1, min(8, (len(PINNED_CPUS) if PINNED_CPUS else (os.cpu_count() or 8) // world) - n_chains))
             self.mesher = BandMesher(N, threads=threads, slots=2 * B)
         mesher = self.mesher
 
@@ -512,6 +557,8 @@ class Job:
             self.pipe.record_timeline = True                  # a few HIP events per round: time_share / per_rank come from them
         torch.cuda.synchronize()
         self.reset_totals()
+        self.dec.sustained_clock_ghz(reset=True)             # warm-up launches are not part of the record
+        startup_s = time.perf_counter() - T_PROCESS_START     # imports, weight synthesis, packing, warm-up: everything before the clock
         barrier(self.world)
         L.surfd_profile_enable(1)
         t0 = time.perf_counter()
@@ -551,7 +598,8 @@ class Job:
         else:
             loop_phase_ms = None
         return {"elapsed": elapsed, "local_elapsed": local_elapsed, "timeline": timeline, "prof": prof, "fwd_total": fwd_total,
-                "grad_total": grad_total, "mesh_stats": mesh_stats, "loop_phase_ms": loop_phase_ms, "steps": steps}
+                "grad_total": grad_total, "mesh_stats": mesh_stats, "loop_phase_ms": loop_phase_ms, "steps": steps,
+                "clock_ghz": self.dec.sustained_clock_ghz(reset=True), "startup_s": startup_s, "rounds": len(timeline) if timeline else None}
 
     def close(self):
         if self.mesher is not None:
@@ -632,13 +680,20 @@ def main():
         import torch.distributed as dist
         fwd_l, fwd_m = prof["dec_fwd"]; grd_l, grd_m = prof["dec_grad"]; lp_n, lp_m = prof["loop"]
         loops_done = max((m.get("loops_done_ms", 0.0) for m in timeline), default=0.0)
-        mine = _host_if_gloo(torch.tensor([local_elapsed * 1e3, lp_m, fwd_m, grd_m, loops_done, fwd_total, float(os.cpu_count() or 0)],
+        mine = _host_if_gloo(torch.tensor([local_elapsed * 1e3, lp_m, fwd_m, grd_m, loops_done, fwd_total, float(os.cpu_count() or 0),
+                                           float(gidx(0)), meas["startup_s"], float(len(PINNED_CPUS) if PINNED_CPUS else 0),
+                                           float(PINNED_CPUS[0] if PINNED_CPUS else -1), meas["clock_ghz"]],
                                           device="cuda", dtype=torch.float64))
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "ms_per_step": float(v[0]) / a.steps, "loop_latency_ms_sum": float(v[1]), "decoder_fwd_ms": float(v[2]),
-                     "decoder_fwd_bwd_ms": float(v[3]), "last_round_loops_done_ms": float(v[4]), "decoder_fwd_queries": float(v[5])}
+                     "decoder_fwd_bwd_ms": float(v[3]), "last_round_loops_done_ms": float(v[4]), "decoder_fwd_queries": float(v[5]),
+                     "first_shape_index": int(v[7]), "startup_s": float(v[8]),
+                     "cpus": (f"{int(v[10])}-{int(v[10]) + int(v[9]) - 1}" if v[9] > 0 else None), "decoder_clock_ghz": float(v[11])}
                     for r, v in enumerate(allr)]
+        for pr in per_rank:          # one line per rank on stderr: a driver timeout or a bent scaling line can be read from the log
+            print(f"[bench] rank {pr['rank']}: ready after {pr['startup_s']:.1f} s, {pr['ms_per_step']:.1f} ms per step, shapes from {pr['first_shape_index']}, "
+                  f"cpus {pr['cpus']}, decoder clock {pr['decoder_clock_ghz']:.2f} GHz", file=sys.stderr)
         tt = _host_if_gloo(torch.tensor([elapsed], device="cuda", dtype=torch.float64))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -679,7 +734,8 @@ def main():
         trace_e2 = {"status": "timed", "value": B * k / tm["elapsed"], "unit": "shapes/s", "steps": k, "warmup": 1, "ms_per_step": tm["elapsed"] / k * 1e3,
                     "workload": f"W-trace ({N}^3 thin shell: {tm['fwd_total'] / (B * k):.0f} forward + {tm['grad_total'] / (B * k):.0f} gradient queries per shape), "
                                 "end point E2 (every mesh finished inside the timed region)",
-                    "roofline": decoder_rooflines(tm, f16),
+                    "roofline": {**decoder_rooflines(tm, f16), "sustained_clock_ghz": tm["clock_ghz"] or None,
+                                 "sustained_clock_means": "shader clock under the forward kernel's launches of this pass (the gradient kernel does not record one)"},
                     "time_share": ({"loops_alone_on_chip_ms": tm["loop_phase_ms"], "loops_frac": tm["loop_phase_ms"] / (tm["elapsed"] * 1e3)}
                                    if tm["loop_phase_ms"] is not None else None),
                     "mesher": tstats}
@@ -726,6 +782,31 @@ def main():
         shapes_in_flight = B * round_steps
     else:
         latents_per_loop_cfg, shapes_in_flight = B, B * (n_chains + 1 if a.schedule == "overlap" else 1)
+    # the loop against the roof that BINDS at the width it ran at: per evaluation the weight stream needs
+    # bytes / HBM peak, the matrix work latents x flops / matrix peak — at 80 latents per loop the matrix work is the larger one.
+    # `frac` = roof time / measured time in the schedule (the loops of a round share the chip: roof time x loops in flight per
+    # wall-clock evaluation); the HBM figure the earlier rounds quoted stays beside it.
+    hbm_us = UNET_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e9) * 1e6
+    mfma_us = flops_eval / (unet_peak * 1e12) * 1e6
+    sched_ms_eval = (loop_phase_ms / (T * max(1, -(-loops // n_chains)))) if (loop_phase_ms and loops) else None     # wall time of one evaluation of the loops running side by side
+    binding = "mfma" if mfma_us >= hbm_us else "hbm"
+    roofline_loop = {"kernel": "conv2_kernel x84 (the head's epilogue carries the posterior update and the loop counter) + attn_kernel x16 per denoiser evaluation (hipGraph replay)",
+                     "bound": binding,
+                     "roof_us_per_evaluation": roof_eval_us, "roof_us_hbm": hbm_us, "roof_us_mfma": mfma_us,
+                     "frac": (n_chains * roof_eval_us * 1e-3 / sched_ms_eval) if sched_ms_eval else (roof_eval_us * 1e-3 / (loop_alone_ms / T)),
+                     "frac_means": "roof time of the loops in flight / wall time per evaluation in the schedule, against the binding roof at this width",
+                     "hbm": {"achieved": streamed_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": streamed_gbs / HBM_PEAK_GBS},
+                     "achieved": (n_chains * flops_eval / (sched_ms_eval * 1e-3) / 1e12) if (sched_ms_eval and binding == "mfma") else streamed_gbs,
+                     "peak": unet_peak if binding == "mfma" else HBM_PEAK_GBS, "unit": "TFLOP/s (algorithmic; x3 issued on the fp16 pipe)" if binding == "mfma" else "GB/s",
+                     "traffic": (pmc or {}).get("unet_eval_hbm_bytes"),
+                     "traffic_from": pmc_note,
+                     "algorithmic_bytes_per_evaluation": UNET_WEIGHT_BYTES, "algorithmic_flop_per_evaluation": flops_eval,
+                     "latents_per_loop": lat_per_loop, "loops_in_flight": n_chains, "loops": loops,
+                     "one_loop_alone_ms_per_evaluation": loop_alone_ms / T,
+                     "one_loop_alone_frac": roof_eval_us * 1e-3 / (loop_alone_ms / T),
+                     "one_loop_alone_us_per_evaluation_and_latent": loop_alone_ms / T * 1e3 / lat_per_loop,
+                     "in_schedule_ms_per_evaluation": loop_ms / max(loops, 1) / T,
+                     "in_schedule_us_per_evaluation_and_latent": (loop_phase_ms * 1e3 / (T * B * a.steps)) if loop_phase_ms else None}
     out = {
         "metric": "shapes/sec end-to-end (1000-step uncond, 512^3 UDF) at 1/2/4/8 GPU",
         "value": shapes / elapsed, "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -745,7 +826,10 @@ def main():
                    "decoder_precision": a.decoder_precision, "unet_precision": a.unet_precision,
                    "fp16_range_saturations": sat,
                    "schedule": a.schedule, "pipeline": sched,
-                   "host_threads_per_rank": {"loop_chains": n_chains, "meshing": (mesh_stats or {}).get("threads", 0), "host_cores": os.cpu_count(), "ranks": world},
+                   "rounds": meas["rounds"], "rounds_means": "time-sliced rounds inside the timed region (loops of a round, then its grids); 1 = the whole region is one round",
+                   "startup_s": meas["startup_s"],
+                   "host_threads_per_rank": {"loop_chains": n_chains, "meshing": (mesh_stats or {}).get("threads", 0), "host_cores": os.cpu_count(), "ranks": world,
+                                             "cpus_of_rank_0": _cpu_ranges(PINNED_CPUS) if PINNED_CPUS else "not pinned (one rank)"},
                    "parallelism": f"shape-parallel x{world}, no data-path collective (latents all_gathered after the timed region)"},
         "roofline": {"kernel": kname, "bound": "mfma",
                      "achieved": algorithmic, "peak": peak, "unit": "TFLOP/s", "frac": algorithmic / peak,
@@ -755,21 +839,15 @@ def main():
                      "launches": fwd_launches, "avg_launch_ms": fwd_ms / max(fwd_launches, 1),
                      "flop_per_point": FWD_FLOP,
                      "issued_tflops": (3.0 if f16 else 1.0) * algorithmic, "issued_frac": (3.0 if f16 else 1.0) * algorithmic / peak,
+                     # the kernel is power-bound: workgroup 0 of every launch measures the shader clock the chip held under it
+                     # (shader cycles / 100 MHz ticks, surfd_decoder_sustained_clock); the matrix peak scales with it
+                     "sustained_clock_ghz": meas["clock_ghz"] or None, "max_clock_ghz": MAX_CLOCK_GHZ,
+                     "clock_limited_peak": (peak * meas["clock_ghz"] / MAX_CLOCK_GHZ) if meas["clock_ghz"] else None,
+                     "frac_of_clock_limited_peak": (algorithmic / (peak * meas["clock_ghz"] / MAX_CLOCK_GHZ)) if meas["clock_ghz"] else None,
+                     "issued_frac_of_clock_limited_peak": ((3.0 if f16 else 1.0) * algorithmic / (peak * meas["clock_ghz"] / MAX_CLOCK_GHZ)) if meas["clock_ghz"] else None,
                      "cus": (f"{a.decoder_blocks} of 256 while loops are in flight, 256 for the last round; peak is the whole chip's")
                             if a.schedule == "overlap" else "256"},
-        "roofline_loop": {"kernel": "conv2_kernel x84 (the head's epilogue carries the posterior update and the loop counter) + attn_kernel x16 per denoiser evaluation (hipGraph replay)",
-                          "bound": "hbm", "achieved": streamed_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": streamed_gbs / HBM_PEAK_GBS,
-                          "traffic": (pmc or {}).get("unet_eval_hbm_bytes"),
-                          "traffic_from": pmc_note,
-                          "algorithmic_bytes_per_evaluation": UNET_WEIGHT_BYTES,
-                          "latents_per_loop": lat_per_loop, "loops_in_flight": n_chains, "loops": loops,
-                          "roof_us_per_evaluation": roof_eval_us,
-                          "one_loop_alone_ms_per_evaluation": loop_alone_ms / T,
-                          "one_loop_alone_frac": roof_eval_us * 1e-3 / (loop_alone_ms / T),
-                          "one_loop_alone_us_per_evaluation_and_latent": loop_alone_ms / T * 1e3 / lat_per_loop,
-                          "in_schedule_ms_per_evaluation": loop_ms / max(loops, 1) / T,
-                          "in_schedule_us_per_evaluation_and_latent": (loop_phase_ms * 1e3 / (T * B * a.steps)) if loop_phase_ms else None},
+        "roofline_loop": roofline_loop,
         "time_share": ({"loops_alone_on_chip_ms": loop_phase_ms, "grids_ms": elapsed * 1e3 - loop_phase_ms,
                         "loops_frac": loop_phase_ms / (elapsed * 1e3)} if loop_phase_ms is not None else None),
         "breakdown_ms_per_step": {"reverse_loop_latency": loop_ms / max(loops, 1), "decoder_fwd": fwd_ms / a.steps,

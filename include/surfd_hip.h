@@ -184,6 +184,11 @@ int surfd_decoder_set_precision(surfd_decoder *d, int mode);
 /* host-sync: waves of the f16x2 forward kernel that produced an activation beyond +-65504 (clamped) since the last
  * reset.  Non-zero = this checkpoint / latent leaves the range mode 1 is exact for: switch to mode 0. */
 int surfd_decoder_saturation_count(surfd_decoder *d, int reset, int64_t *count, surfd_stream s);
+/* Shader clock (GHz) the chip sustained under the forward decoder kernel since the last reset: workgroup 0 of every launch of the
+ * 8-wave forward kernel adds its shader-cycle and 100 MHz real-time differences to a device-side record (the kernel is
+ * power-bound: its rate follows this clock, bench.py `roofline.sustained_clock_ghz`).  0 when no launch ran.  Measurement aid,
+ * no reference counterpart. */
+int surfd_decoder_sustained_clock(surfd_decoder *d, int reset, double *ghz, surfd_stream s);
 /* The decoder kernels are persistent: `blocks` workgroups (one per CU, LDS-limited) loop over the point tiles.
  * 0 (default) = every CU.  A smaller value leaves CUs free for work on another stream (bench.py overlaps the
  * reverse loop of the next batch with the grid evaluation of the current one this way). */

@@ -71,6 +71,7 @@ _SIGS = {
     "surfd_decoder_finalize": (C.c_int, [_P, _P]),
     "surfd_decoder_set_precision": (C.c_int, [_P, C.c_int]),
     "surfd_decoder_saturation_count": (C.c_int, [_P, C.c_int, c_i64p, _P]),
+    "surfd_decoder_sustained_clock": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), _P]),
     "surfd_decoder_set_grid_blocks": (C.c_int, [_P, C.c_int]),
     "surfd_decoder_bind_latents": (C.c_int, [_P, _P, C.c_int, _P]),
     "surfd_decoder_logits_emb": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, _P]),

@@ -198,6 +198,15 @@ class CbnDecoder(nn.Module):
         N.check(L.surfd_decoder_saturation_count(h, int(reset), C.byref(n), N.stream()))
         return int(n.value)
 
+    def sustained_clock_ghz(self, reset: bool = True) -> float:
+        """Shader clock the chip held under the 8-wave forward kernel since the last reset (0.0: no launch) — the kernel is
+        power-bound, so its reachable peak is the matrix peak times this over 2.4 GHz (bench.py roofline.sustained_clock_ghz)."""
+        import ctypes as C
+        L, h = self._native()
+        g = C.c_double()
+        N.check(L.surfd_decoder_sustained_clock(h, int(reset), C.byref(g), N.stream()))
+        return float(g.value)
+
     def set_grid_blocks(self, blocks: int) -> None:
         """Persistent workgroups per decoder launch (0 = one per CU); fewer leaves CUs to other streams."""
         L, h = self._native()

@@ -1298,6 +1298,15 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     lds_u32 *xw0 = (lds_u32 *)(reinterpret_cast<unsigned *>(X) + (4 * (lane >> 5)) * XS + 32 * wave + col);
     lds_u32 *xw1 = xw0 + 32 * XS;
 #define XW8(mt, r, pl) ((mt) ? xw1 : xw0)[(((r) & 3) + 8 * ((r) >> 2)) * XS + 256 * (pl)]
+    // Sustained shader clock of this launch: the kernel is power-bound, its rate follows the clock the chip can
+    // hold under it.  Workgroup 0 (persistent: it runs from the first tile to the last) notes the shader-cycle counter and the
+    // 100 MHz real-time counter now and adds the differences to the handle's record when it leaves; the start values wait in
+    // memory, not in registers (the kernel sits at its 256-register / SGPR limit).
+    unsigned long long *const clk = reinterpret_cast<unsigned long long *>(P.sat + 2);
+    if (blockIdx.x == 0 && tid == 0) {
+        clk[0] = (unsigned long long)__builtin_readcyclecounter();
+        clk[1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    }
     int sat_flag = 0;
     // X <- split(min(relu(a*v + b), 65504)) for this wave's 64 channels x 64 points
     auto store8 = [&](const f32x16 (&v)[2][2], const float (&sa)[2], const float (&sb)[2]) {
@@ -1465,6 +1474,11 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     }
     }
     if (sat_flag && lane == 0) atomicAdd(P.sat, 1u);
+    if (blockIdx.x == 0 && tid == 0) {
+        const unsigned long long c1 = (unsigned long long)__builtin_readcyclecounter(), r1 = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        atomicAdd(clk + 2, c1 - clk[0]);
+        atomicAdd(clk + 3, r1 - clk[1]);
+    }
 }
 #undef XAT8
 #undef XW8
@@ -1605,9 +1619,11 @@ static int dec_alloc(surfd_decoder *d) {
     if ((rc = A(&d->vecs, VEC_FLOATS))) return rc;
     HIP_TRY(hipMalloc((void **)&d->whf, WHF_ELEMS * sizeof(_Float16)));
     d->allocs.push_back(d->whf);
-    HIP_TRY(hipMalloc((void **)&d->sat, sizeof(unsigned)));
+    // [0]: saturation counter; 8 bytes in: the clock record of the 8-wave forward kernel {start cycles, start ticks, sum of shader
+    // cycles, sum of 100 MHz ticks} (surfd_decoder_sustained_clock)
+    HIP_TRY(hipMalloc((void **)&d->sat, 8 + 4 * sizeof(unsigned long long)));
     d->allocs.push_back(d->sat);
-    HIP_TRY(hipMemset(d->sat, 0, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d->sat, 0, 8 + 4 * sizeof(unsigned long long)));
     if (const char *pe = getenv("SURFD_DECODER_PRECISION")) d->precision = !strcmp(pe, "fp32") ? 0 : 1;
     if (const char *pe = getenv("SURFD_DECODER_FWD8")) d->fwd8 = atoi(pe) != 0;
     for (int l = 0; l < NCBN; ++l) {
@@ -1812,6 +1828,20 @@ int surfd_decoder_saturation_count(surfd_decoder *d, int reset, int64_t *count, 
     if (reset) HIP_TRY(hipMemsetAsync(d->sat, 0, sizeof(v), st));
     HIP_TRY(hipStreamSynchronize(st));
     *count = v;
+    return SURFD_OK;
+}
+
+int surfd_decoder_sustained_clock(surfd_decoder *d, int reset, double *ghz, surfd_stream s) {
+    if (!d || !ghz) SURFD_FAIL(SURFD_ERR_ARG, "surfd_decoder_sustained_clock: null argument");
+    *ghz = 0.0;
+    if (!d->sat) return SURFD_OK;
+    unsigned long long v[4] = {0, 0, 0, 0};
+    hipStream_t st = as_stream(s);
+    unsigned long long *clk = reinterpret_cast<unsigned long long *>(d->sat + 2);
+    HIP_TRY(hipMemcpyAsync(v, clk, sizeof(v), hipMemcpyDeviceToHost, st));
+    if (reset) HIP_TRY(hipMemsetAsync(clk + 2, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (v[3] > 0) *ghz = (double)v[2] / ((double)v[3] * 10.0);        // cycles per 10 ns tick = GHz x 10
     return SURFD_OK;
 }
 

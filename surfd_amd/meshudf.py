@@ -273,7 +273,7 @@ class GridFiller:
                     capacity = grad_capacity = None
                     continue
             if cut:
-                raise RuntimeError(f"fill_grid_sharded: exchange capacities {caps} / {gcap} gradient points are too small for this field "
+                raise RuntimeError(f"fill_grid_sharded: exchange capacity too small for this field: per level {caps}, gradient points {gcap} "
                                    f"(levels over: {over}, gradient points {self.last_stats['grad']} of {gcap}): pass larger ones, or adaptive=True")
             break
         return udf, grads

@@ -102,3 +102,18 @@ def test_committed_traffic_is_what_the_tool_derives(tmp_path, bench):
         assert prof == on_disk and "unchanged" in note
     else:
         assert prof is None and ("stale" in note or "does not name" in note)
+
+
+def test_rank_cpu_placement(bench):
+    """every rank of an N-rank run keeps an equal contiguous slice of the host's CPUs for its loop threads, meshing
+    threads and torch's pool (os.sched_setaffinity in setup_dist); one rank, or a host with fewer than two CPUs per rank, is
+    left alone."""
+    cpus = list(range(64))
+    slices = [bench.rank_cpu_slice(cpus, 8, r) for r in range(8)]
+    assert all(len(s) == 8 for s in slices) and sorted(c for s in slices for c in s) == cpus        # disjoint, complete
+    assert slices[3] == list(range(24, 32))
+    assert bench.rank_cpu_slice(cpus, 1, 0) is None and bench.rank_cpu_slice(list(range(8)), 8, 0) is None
+    odd = [0, 1, 2, 3, 8, 9, 10, 11, 12, 13]                                                         # a restricted affinity mask
+    assert bench.rank_cpu_slice(odd, 2, 1) == [9, 10, 11, 12, 13]
+    assert bench._cpu_ranges(odd) == "0-3,8-13" and bench._cpu_ranges([5]) == "5"
+    assert bench.MAX_CLOCK_GHZ == 2.4

@@ -48,3 +48,40 @@ def test_two_ranks_over_gloo_on_one_gpu():
     assert [p["rank"] for p in pr] == [0, 1] and all(p["ms_per_step"] > 0 and p["decoder_fwd_queries"] > 0 for p in pr)
     assert pr[0]["decoder_fwd_queries"] != pr[1]["decoder_fwd_queries"]                         # the ranks sampled different shapes
     assert max(p["ms_per_step"] for p in pr) <= d["ms_per_step"] * 1.01
+
+
+@pytest.mark.parametrize("mode", ["shape-parallel", "grid-shard"])
+def test_eight_ranks_over_gloo_on_one_gpu(mode):
+    """The command line the driver uses for its 8-GPU scaling run, exercised on the one GPU this box has: 8 ranks over the gloo
+    development backend sharing the device (64^3, 20 DDIM steps).  What can fail for a reason knowable on one GPU fails here:
+    launcher, rank placement, rendezvous, per-rank shape indices, barriers, the gathers of the line, and in grid-shard mode
+    the native exchange protocol with 8 ranks (tiles r, r + 8, ..., per-level capacities, overflow counter)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SURFD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    small = ["--steps", "2", "--warmup", "0", "--diffusion-steps", "20", "--resolution", "64", "--no-trace", "--no-e2", "--no-cpu-baseline", "--mode", mode]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8"] + small
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _line(out.stdout)
+    assert d["n_gpus"] == 8 and d["value"] > 0
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8)) and all(p["ms_per_step"] > 0 for p in pr)
+    if mode == "shape-parallel":
+        assert d["scaling"] == "weak" and d["rccl_ranks"] == 8
+        assert d["value"] == pytest.approx(8 * 8 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
+        firsts = [p["first_shape_index"] for p in pr]
+        assert firsts == [r * 8 for r in range(8)]                      # step 0: rank r samples the global shapes 8 r ... 8 r + 7
+        assert all(p["decoder_fwd_queries"] >= 2 * 8 * 32 ** 3 for p in pr)
+        assert all(p["startup_s"] > 0 for p in pr)
+        ncpu = len(os.sched_getaffinity(0))
+        if ncpu >= 16:                                                   # two or more CPUs per rank: every rank is pinned to its own slice
+            cp = [p["cpus"] for p in pr]
+            assert all(c for c in cp) and len(set(cp)) == 8
+        assert "rank 7: ready after" in out.stderr
+    else:
+        assert d["scaling"] == "strong" and d["config"]["mode"] == "grid-shard"
+        assert d["config"]["exchange_buffers_cut_in_timed_region"] == 0 and d["config"]["exchange_bytes_per_shape"] > 0
+        assert len(d["config"]["exchange_capacity_points"]["per_level"]) == 2      # 64^3: the 32^3 lattice and one refinement, each with its own capacity

@@ -796,28 +796,28 @@ def test_grid_shard_protocol_state_is_checked():
     smp = dec._bind_single(lat)
     st = N.stream()
     udf = torch.empty(64, 64, 64, device="cuda"); grads = torch.empty(64, 64, 64, 3, device="cuda")
-    buf = torch.zeros(1 << 18, device="cuda")
+    buf = torch.zeros(3 << 18, device="cuda")
     ERR_STATE = -2
-    cap = 32 ** 3
+    cap, gcap = 32 ** 3, 1 << 18                            # gradient capacity = every voxel of the 64^3 grid
     assert L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st) == ERR_STATE          # nothing open
     N.check(L.surfd_grid_shard_begin(h, N.ptr(udf), N.ptr(grads), st))
     assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st) == ERR_STATE                       # commit before eval
     assert L.surfd_grid_shard_level_eval(h, dh, smp, 1, 0, 1, N.ptr(buf), 1 << 18, st) == ERR_STATE     # level 1 before level 0
-    assert L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), 1 << 16, st) == ERR_STATE         # gradients before the levels
+    assert L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), gcap, st) == ERR_STATE            # gradients before the levels
     N.check(L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st))
     assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap - 64, st) == ERR_STATE                  # another capacity than the eval
     N.check(L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st))
     assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st) == ERR_STATE                       # level 0 is closed
     N.check(L.surfd_grid_shard_level_eval(h, dh, smp, 1, 0, 1, N.ptr(buf), 1 << 18, st))
     N.check(L.surfd_grid_shard_level_commit(h, 1, N.ptr(buf), 1 << 18, st))
-    assert L.surfd_grid_shard_grad_commit(h, N.ptr(buf), 1 << 16, st) == ERR_STATE                       # gradient commit before its eval
-    N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), 1 << 16, st))
-    N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(buf), 1 << 16, st))
+    assert L.surfd_grid_shard_grad_commit(h, N.ptr(buf), gcap, st) == ERR_STATE                          # gradient commit before its eval
+    N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), gcap, st))
+    N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(buf), gcap, st))
     assert L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st) == ERR_STATE          # the fill is closed
     # what the protocol produced is the fused fill's grid
     a, b = GridFiller(64).fill_grid(f, 2 ** 16)
     torch.cuda.synchronize()
-    assert torch.equal(a, udf) and torch.equal(b, grads)
+    assert torch.equal(a, udf) and torch.equal(b, grads) and gf.shard_overflows() == 0
 
 
 def _native_shard_worker(rank, world, port, out, backend):
