@@ -87,6 +87,11 @@ struct Conv2Args {
                            // loop-counter advance in the epilogue.  A pointer, and its own instantiation: the other 83 launches of an
                            // evaluation must not carry a byte or a register of it
     long long *dbg;        // -DSURFD_C2_STAMPS builds: 16 phase stamps (100 MHz ticks) of workgroup 0
+    // weight prefetch ahead (SURFD_C2_PFN): the NEXT convolution's packed weights and how its launch will cut them up
+    const char *pf_w;      // null: nothing to request
+    int pf_ntiles, pf_KS16, pf_KS, pf_G, pf_nblk0, pf_it0, pf_nch, pf_it1;
+    int pf_log2tpg, pf_log2bps, pf_log2lpb;   // tiles per group (1 / 4), K blocks per slice and 128-byte lines per K block, rounded up to powers of two
+    unsigned pf_magic_ks;
 };
 
 #ifndef SURFD_C2_EPI_LATE
@@ -128,21 +133,22 @@ __device__ __forceinline__ float silu2(float v) {
 // seven batches, each behind an s_waitcnt lgkmcnt(0) and each touching lines the scalar cache has not seen in this launch
 // (the segment was last read one graph replay = 553 MB of weight stream ago): seven dependent misses before the first
 // operand load can be issued.  One dword of every line requested by the first instructions of the wave turns them into one
-// miss and six hits.
+// miss and seven hits.
 #ifndef SURFD_C2_KAPF
 #define SURFD_C2_KAPF 1
 #endif
 template <int BYTES>
 __device__ __forceinline__ void c2_kernarg_prefetch() {
 #if SURFD_C2_KAPF
-    static_assert(BYTES > 0x180 && BYTES <= 0x1c0, "kernel-argument prefetch covers seven 64-byte lines");
+    static_assert(BYTES > 0x1c0 && BYTES <= 0x200, "kernel-argument prefetch covers eight 64-byte lines");
     const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-    int d0, d1, d2, d3, d4, d5, d6;
+    int d0, d1, d2, d3, d4, d5, d6, d7;
     // the wait is part of the statement: the destinations are dead when it ends (no compiler-assigned value can be hit by a late
     // return), and it costs nothing — the compiler's own first batch would wait for the same miss two instructions later
-    asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
-                 "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) : "s"(ka));
+    asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
+                 "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7) : "s"(ka));
 #endif
 }
 
@@ -237,6 +243,61 @@ __device__ __forceinline__ void lds_bar() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// Weight prefetch ahead (SURFD_C2_PFN).  A wave of the wide form runs its whole K slice against a ring of four k16 steps; every
+// step waits for a round trip, and the weights come from HBM every time (553 MB per evaluation against 32 MB of L2): 214 ns per
+// k16 step against 40 ns of matrix time — and 136 ns when the same launch is repeated and finds its weights in the L2s
+// (profiles/r05_loop_experiments.md, SURFD_CONV2_TWICE).  So every workgroup requests its share of the NEXT convolution's
+// weights — the slices that launch's workgroups on THIS XCD will stream (block b runs on XCD b % 8; the next launch's group
+// g = (row group, K slice) runs on XCD g % 8, or everywhere when it has fewer than 8 groups): C2_PFN_N four-byte loads per
+// thread, one per 128-byte line, issued right behind this block's own first requests and "used" by an empty statement at the
+// very end.  Ordinary, unconditional loads: the compiler's vmcnt arithmetic stays exact (a request it does not know about in
+// front of the ring would make every ring wait stricter; requests at the exit — the first form of this — made every workgroup
+// end 1.5 us later: S_ENDPGM waits for them).  The XCD's line set is indexed uniformly: (group of this XCD, tile of the group,
+// K block of the slice, line) with every block padded to the longer segment's length; padding and missing blocks re-read the
+// first line.
+#ifndef SURFD_C2_PFN
+#define SURFD_C2_PFN 1
+#endif
+constexpr int C2_PFN_N = 2;
+__device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, unsigned (&sink)[C2_PFN_N]) {
+#if SURFD_C2_PFN
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int x = bid & 7, i = bid >> 3, nx = (nwg + 7 - x) >> 3;            // this workgroup is number i of nx on XCD x
+    const bool all = A.pf_G < 8;                                              // fewer than 8 groups: every XCD streams every group
+    const int ngx = all ? A.pf_G : (A.pf_G + 7 - x) >> 3;                     // groups whose weights this XCD will read
+    // index space, powers of two throughout (shifts, no divisions in front of the operand wait):
+    //   ((group of this XCD * tiles per group + tile) * blocks per slice + block) * lines per block + line
+    const int sl = A.pf_log2lpb, sb = A.pf_log2bps, st = A.pf_log2tpg;
+    const char *w = A.pf_w;                                                   // never null: the host points it at this launch's own weights when there is nothing to request
+    long off[C2_PFN_N];
+#pragma unroll
+    for (int k = 0; k < C2_PFN_N; ++k) off[k] = 0;
+    if (A.pf_ntiles > 0) {                                                    // wave-uniform; the loads below are issued either way
+#pragma unroll
+        for (int k = 0; k < C2_PFN_N; ++k) {
+            const unsigned p = (unsigned)(i + k * nx) * 256u + (unsigned)tid;
+            const int l = (int)(p & ((1u << sl) - 1u));
+            const unsigned r1 = p >> sl;
+            const int j = (int)(r1 & ((1u << sb) - 1u));
+            const unsigned r2 = r1 >> sb;
+            const int tl = (int)(r2 & ((1u << st) - 1u)), q = (int)(r2 >> st);
+            const int g = all ? q : x + 8 * q;
+            const int rg = A.pf_KS == 1 ? g : (int)__umulhi((unsigned)g, A.pf_magic_ks), kz = g - rg * A.pf_KS;      // g / KS: host-made reciprocal, g < 2^16
+            const int tile = (rg << st) + tl, ch = kz + j * A.pf_KS;
+            const int it = ch < A.pf_nblk0 ? A.pf_it0 : A.pf_it1;
+            const long k16 = ch < A.pf_nblk0 ? (long)ch * A.pf_it0 : (long)A.pf_nblk0 * A.pf_it0 + (long)(ch - A.pf_nblk0) * A.pf_it1;
+            const bool ok = q < ngx && tile < A.pf_ntiles && ch < A.pf_nch && l < it * 16;
+            off[k] = ok ? (((long)tile * A.pf_KS16 + k16) * 2048 + (long)l * 128) : 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < C2_PFN_N; ++k) sink[k] = *reinterpret_cast<const unsigned *>(w + off[k]);
+#else
+#pragma unroll
+    for (int k = 0; k < C2_PFN_N; ++k) sink[k] = 0u;
+#endif
 }
 
 // VEC: float4 registers a thread holds while staging its channel (8: operand rows of 4..32 positions,
@@ -456,6 +517,8 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     issue_operand(ch, v, ga, be);
 #pragma unroll
     for (int d = 0; d < C2_D; ++d) load_group(ring[d], cur.base, cur.it_beg + d * C2_U, cur.it_end - 1);
+    unsigned pf_sink[C2_PFN_N];
+    c2_prefetch_next(A, tid, pf_sink);                 // the next convolution's weights, towards this XCD's L2
 
     // ---- epilogue operands (bias + per-(step, sample) embedding + residual), requested now, used at the end ----
     // kept as three separate register sets and only combined in the epilogue: combining them here would put a
@@ -929,6 +992,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             }
         }
     }
+    asm volatile("" :: "v"(pf_sink[0]), "v"(pf_sink[1]));      // the prefetched words' only "use": the compiler counts them as loads in flight until here
 #ifdef SURFD_C2_STAMPS
     C2_STAMP(9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1336,6 +1400,38 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     dim3 grid((unsigned)(G < 8 ? G * A.nby : 8 * ceil_div(G, 8) * A.nby));
     static const int pref = env_int("SURFD_CONV2_PREF", 0);      // operand prefetch across K blocks: measured 1.472 (on) vs 1.442 ms (off) per evaluation
     static const int wpref = env_int("SURFD_CONV2_WIDE_PREF", 0);
+    // this launch's shape for the launch before it (next evaluation on: the loop replays the same launches), and the next
+    // convolution's shape for this one
+    {
+        ConvPlan::LaunchRec &R = c.rec;
+        R.gen = u->ws_gen; R.B = B; R.L = L; R.whf = A.whf; R.ntiles = A.ntiles; R.KS16 = A.KS16; R.tpg = wt ? 4 : 1; R.KS = KS; R.G = A.nrt * KS;
+        R.nblk0 = A.seg[0].nblk; R.it0 = A.seg[0].taps * (A.seg[0].blkp >> 4);
+        R.nch = A.seg[0].nblk + (c.nseg > 1 ? A.seg[1].nblk : 0); R.it1 = c.nseg > 1 ? A.seg[1].taps * (A.seg[1].blkp >> 4) : 0;
+    }
+    // nothing to request (first evaluation, other shape, switched off): every thread re-reads the first line of this launch's own
+    // weights — the loads are unconditional by design
+    A.pf_w = reinterpret_cast<const char *>(A.whf);
+    A.pf_ntiles = 0; A.pf_KS16 = 0; A.pf_KS = 1; A.pf_G = 1; A.pf_nblk0 = 1; A.pf_it0 = 1; A.pf_nch = 1; A.pf_it1 = 1;
+    A.pf_log2tpg = 0; A.pf_log2bps = 0; A.pf_log2lpb = 4; A.pf_magic_ks = 0u;
+    static const int pfn_env = env_int("SURFD_CONV2_PFN", 1);
+    // Requested where it pays: the request costs this launch ~1 us of issue time (two loads of 64 different lines per wave in
+    // front of the wait for the operand), the next launch's K loop gets ~35 % shorter — 2-5 us on a three-tap convolution over
+    // 224-channel blocks (42 k16 steps per block), 0.9 us on a 1 x 1 convolution (14): the wide form requests when the next
+    // launch runs >= SURFD_CONV2_PFN_MIN k16 steps per wave; the latency form (a wave's k-part is ~10 steps, 8 of them in
+    // flight before the operand is staged) never does (1.40 against 1.38 ms per evaluation at 8 latents).
+    static const int pfn_min = env_int("SURFD_CONV2_PFN_MIN", 28);
+    if (pfn_env && wt && u->pf_next && u->pf_next != &c) {
+        const ConvPlan::LaunchRec &R = u->pf_next->rec;
+        const int steps_per_wave = ceil_div(R.nch, std::max(R.KS, 1)) * std::max(R.it0, R.it1);
+        if (R.gen == u->ws_gen && R.B == B && R.L == L && R.whf && R.tpg == 4 && steps_per_wave >= pfn_min) {
+            A.pf_w = reinterpret_cast<const char *>(R.whf);
+            A.pf_ntiles = R.ntiles; A.pf_KS16 = R.KS16; A.pf_KS = R.KS; A.pf_G = R.G;
+            A.pf_nblk0 = R.nblk0; A.pf_it0 = R.it0; A.pf_nch = R.nch; A.pf_it1 = std::max(R.it1, 1);
+            auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+            A.pf_log2tpg = lg(R.tpg); A.pf_log2bps = lg(ceil_div(R.nch, R.KS)); A.pf_log2lpb = lg(16 * std::max(R.it0, R.it1));
+            A.pf_magic_ks = (unsigned)((0x100000000ULL + R.KS - 1) / R.KS);
+        }
+    }
     auto launch = [&]() {
         if (A.lf) {         // the head of a graph-replayed loop: same decompositions, posterior update in the epilogue
             if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true, false, true>), grid, dim3(256), lds, st, A);

@@ -1302,11 +1302,16 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     // hold under it.  Workgroup 0 (persistent: it runs from the first tile to the last) notes the shader-cycle counter and the
     // 100 MHz real-time counter now and adds the differences to the handle's record when it leaves; the start values wait in
     // memory, not in registers (the kernel sits at its 256-register / SGPR limit).
+#ifndef SURFD_DEC_CLOCK
+#define SURFD_DEC_CLOCK 1
+#endif
+#if SURFD_DEC_CLOCK
     unsigned long long *const clk = reinterpret_cast<unsigned long long *>(P.sat + 2);
     if (blockIdx.x == 0 && tid == 0) {
         clk[0] = (unsigned long long)__builtin_readcyclecounter();
         clk[1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     }
+#endif
     int sat_flag = 0;
     // X <- split(min(relu(a*v + b), 65504)) for this wave's 64 channels x 64 points
     auto store8 = [&](const f32x16 (&v)[2][2], const float (&sa)[2], const float (&sb)[2]) {
@@ -1474,11 +1479,13 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     }
     }
     if (sat_flag && lane == 0) atomicAdd(P.sat, 1u);
+#if SURFD_DEC_CLOCK
     if (blockIdx.x == 0 && tid == 0) {
         const unsigned long long c1 = (unsigned long long)__builtin_readcyclecounter(), r1 = (unsigned long long)__builtin_amdgcn_s_memrealtime();
         atomicAdd(clk + 2, c1 - clk[0]);
         atomicAdd(clk + 3, r1 - clk[1]);
     }
+#endif
 }
 #undef XAT8
 #undef XW8

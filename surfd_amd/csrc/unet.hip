@@ -1527,8 +1527,17 @@ int unet_forward_prepared(surfd_unet *u, const float *x, int row0, float *out, i
         const float *in[2] = {u->emb_ctx, nullptr}; const long bs[2] = {u->ted, 0}; const int bm[2] = {0, 0};
         if ((rc = launch_conv(u, u->lin3, B, 1, in, bs, bm, u->emb_table, u->emb_total, nullptr, 0, st, step_ptr, nullptr, nullptr, u->emb, u->ted))) return rc;
     }
-    for (auto &op : u->ops)
-        if ((rc = run_op(u, op, x, out, B, L, emb, st, step_ptr, lf, lf_done))) return rc;
+    // every convolution learns which convolution follows it (attention launches in between do not count; after the head the
+    // next evaluation's first one): it requests that layer's weights while it finishes (conv_f16x2.hip, SURFD_C2_PFN)
+    const ConvPlan *first_conv = nullptr;
+    for (auto &op : u->ops) if (op.kind == 0) { first_conv = &op.conv; break; }
+    for (size_t i = 0; i < u->ops.size(); ++i) {
+        u->pf_next = first_conv;
+        for (size_t j = i + 1; j < u->ops.size(); ++j) if (u->ops[j].kind == 0) { u->pf_next = &u->ops[j].conv; break; }
+        rc = run_op(u, u->ops[i], x, out, B, L, emb, st, step_ptr, lf, lf_done);
+        u->pf_next = nullptr;
+        if (rc) return rc;
+    }
     return SURFD_OK;
 }
 

@@ -47,6 +47,14 @@ struct ConvPlan {
     int blk2[2] = {0, 0}, blkp2[2] = {0, 0}, nblk2[2] = {0, 0}, k16_off2[2] = {0, 0};
     int KS16_2 = 0;
     size_t whf2_off = 0;
+    // what the last launch of this convolution on the f16x2 kernel looked like (launch_conv2): the launch BEFORE it uses the
+    // record to request this layer's weight slices into the L2 of the XCD that will read them (conv_f16x2.hip, SURFD_C2_PFN)
+    struct LaunchRec {
+        long gen = -1; int B = 0, L = 0;
+        const _Float16 *whf = nullptr;
+        int ntiles = 0, KS16 = 0, tpg = 1, KS = 1, G = 1, nblk0 = 0, it0 = 0, nch = 0, it1 = 0;
+    };
+    mutable LaunchRec rec;
 };
 
 struct AttnPlan { View qkv, out; int C = 0, ds = 1; };
@@ -97,6 +105,7 @@ struct surfd_unet {
     int cu_budget = 256;                               // CUs this context's launches can count on (split-K sizing)
     int precision = 1;                                 // denoiser conv arithmetic: 1 = f16x2 (default), 0 = exact fp32 MFMA
     int dbg_only = -1;                                 // >= 0: only this conv op runs on the f16x2 kernel (surfd_unet_debug_only_op)
+    const surfd::ConvPlan *pf_next = nullptr;          // the convolution that runs after the one being launched (weight prefetch ahead)
     long ws_gen = 1;                                   // bumped whenever a buffer baked into the cached loop graph is reallocated
 };
 
