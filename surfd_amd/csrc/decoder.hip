@@ -1302,6 +1302,15 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     // hold under it.  Workgroup 0 (persistent: it runs from the first tile to the last) notes the shader-cycle counter and the
     // 100 MHz real-time counter now and adds the differences to the handle's record when it leaves; the start values wait in
     // memory, not in registers (the kernel sits at its 256-register / SGPR limit).
+    // Experiment (-DSURFD_DEC_XCD_STAGGER=k, default off): the workgroups of XCD x (block b runs on XCD b % 8)
+    // start x * k sleeps of ~4.8 us late, so that the eight XCDs walk the 11 layers out of phase (k = 6: an eighth of a tile's
+    // ~215 us per XCD) instead of fetching the same 1 MB of a layer's planes from the fabric at the same moment.
+#ifndef SURFD_DEC_XCD_STAGGER
+#define SURFD_DEC_XCD_STAGGER 0
+#endif
+#if SURFD_DEC_XCD_STAGGER > 0
+    for (int k_ = 0; k_ < (int)(blockIdx.x & 7) * SURFD_DEC_XCD_STAGGER; ++k_) __builtin_amdgcn_s_sleep(127);
+#endif
 #ifndef SURFD_DEC_CLOCK
 #define SURFD_DEC_CLOCK 1
 #endif

@@ -4,7 +4,7 @@
 # MI355X_MICROARCH.md prescribes) on a shortened run of the same kernels.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04prof; mkdir -p $O
+O=gpurun_out/r05prof; mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-trace --no-e2 --no-strict --no-trace-e2 > $O/bench_under_rocprof.json 2> $O/kt.log
 SHORT="python bench.py --steps 20 --warmup 0 --diffusion-steps 20 --no-cpu-baseline --no-trace --no-e2 --no-strict --no-trace-e2"      # the driver's 20 steps (loops of 80 latents, all grids), 20 instead of 1000 loop iterations
@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_A
 # keep only the summaries (the raw traces are large)
 python - <<'PY'
 import csv, collections, glob, json, os
-O = "gpurun_out/r04prof"
+O = "gpurun_out/r05prof"
 def agg(path, col):
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
