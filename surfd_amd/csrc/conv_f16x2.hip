@@ -92,6 +92,7 @@ struct Conv2Args {
     int pf_ntiles, pf_KS16, pf_KS, pf_G, pf_nblk0, pf_it0, pf_nch, pf_it1;
     int pf_log2tpg, pf_log2bps, pf_log2lpb;   // tiles per group (1 / 4), K blocks per slice and 128-byte lines per K block, rounded up to powers of two
     unsigned pf_magic_ks;
+    int off_pf;            // byte offset of 256 bytes of LDS nobody reads: where the requested words land (SURFD_C2_PFN_DMA)
 };
 
 #ifndef SURFD_C2_EPI_LATE
@@ -112,7 +113,13 @@ struct Conv2Args {
 #define SURFD_C2_LEAN_WAVES 3          // waves per SIMD (= workgroups per CU) the lean form is compiled for: 3 -> 168 VGPRs, no spills
 #endif
 constexpr int C2_PLANE_NT2 = 13056;    // two column tiles per wave: 96 positions x (128 + 8) halfs; 2 planes + flag = 52 240 B, three workgroups per CU
-constexpr int C2_PLANE_LEAN = 10112;   // halfs per fp16 plane of the slab in the lean form: 2 planes + flag = 40 464 B, four workgroups per CU
+#ifndef SURFD_C2_PLANE_LEAN
+#define SURFD_C2_PLANE_LEAN 11264
+#endif
+// halfs per fp16 plane of the slab in the lean form.  Round 4: 10 112 (2 planes + flag = 40 464 B: room for a fourth workgroup per CU
+// that the 168-register build never uses); 11 264 holds EIGHT samples of the 4-position level (8 x 6 x 232 = 11 136 halfs)
+// instead of seven: 10 full 32-column chunks per 80 latents instead of 11 + a tail of three; 3 x 45 072 B of the CU's 160 KB
+constexpr int C2_PLANE_LEAN = SURFD_C2_PLANE_LEAN;
 
 // SiLU of the operand staging: x * 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp).  __frcp_rn is an IEEE
 // division on this target — v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: ten instructions per value, a
@@ -260,8 +267,18 @@ __device__ __forceinline__ void lds_bar() {
 #ifndef SURFD_C2_PFN
 #define SURFD_C2_PFN 1
 #endif
-constexpr int C2_PFN_N = 2;
-__device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, unsigned (&sink)[C2_PFN_N]) {
+#ifndef SURFD_C2_PFN_N
+#define SURFD_C2_PFN_N 1
+#endif
+constexpr int C2_PFN_N = SURFD_C2_PFN_N;
+// SURFD_C2_PFN_DMA=1 (experiment, off): the request as an LDS-DMA load instead of an ordinary one — no destination register, so
+// the one register the lean form spills for it (and the wait that spill implies) would go away.  Measured SLOWER (2 x 80 latents
+// 3.17 against 3.08-3.14 ms per evaluation), and M0's 16-bit LDS base wraps in the two-per-CU forms (74 KB of LDS: the word
+// landed in the slab).
+#ifndef SURFD_C2_PFN_DMA
+#define SURFD_C2_PFN_DMA 0
+#endif
+__device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, unsigned (&sink)[C2_PFN_N], unsigned lds_dst) {
 #if SURFD_C2_PFN
     const int bid = blockIdx.x, nwg = gridDim.x;
     const int x = bid & 7, i = bid >> 3, nx = (nwg + 7 - x) >> 3;            // this workgroup is number i of nx on XCD x
@@ -292,8 +309,25 @@ __device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, un
             off[k] = ok ? (((long)tile * A.pf_KS16 + k16) * 2048 + (long)l * 128) : 0;
         }
     }
+#if SURFD_C2_PFN_DMA
+    // The request as an LDS-DMA load (global_load_lds_dword: the word lands in 256 bytes of LDS nobody reads — no destination
+    // register).  As an ordinary load the word needed a register from here to the end of a kernel that has none to spare: the
+    // compiler spilled it, and a spill is a store of the LOADED value — an s_waitcnt vmcnt(0) right here, in front of the wait
+    // for the operand (read back from the code object).  The compiler does not count this request; it is the youngest when
+    // issued and long complete when the ring's counted waits begin.  M0 (the DMA's LDS base) is set and restored inside the
+    // statement.
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
+#pragma unroll
+    for (int k = 0; k < C2_PFN_N; ++k) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(w + off[k]), "s"(dst) : "memory");
+        sink[k] = 0u;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < C2_PFN_N; ++k) sink[k] = *reinterpret_cast<const unsigned *>(w + off[k]);
+#endif
 #else
 #pragma unroll
     for (int k = 0; k < C2_PFN_N; ++k) sink[k] = 0u;
@@ -518,7 +552,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #pragma unroll
     for (int d = 0; d < C2_D; ++d) load_group(ring[d], cur.base, cur.it_beg + d * C2_U, cur.it_end - 1);
     unsigned pf_sink[C2_PFN_N];
-    c2_prefetch_next(A, tid, pf_sink);                 // the next convolution's weights, towards this XCD's L2
+    c2_prefetch_next(A, tid, pf_sink, (unsigned)(size_t)(lds_raw + A.off_pf));     // the next convolution's weights, towards this XCD's L2
 
     // ---- epilogue operands (bias + per-(step, sample) embedding + residual), requested now, used at the end ----
     // kept as three separate register sets and only combined in the epilogue: combining them here would put a
@@ -992,7 +1026,12 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             }
         }
     }
-    asm volatile("" :: "v"(pf_sink[0]), "v"(pf_sink[1]));      // the prefetched words' only "use": the compiler counts them as loads in flight until here
+    {   // the prefetched words' only "use": the compiler counts them as loads in flight until here
+        unsigned used = 0u;
+#pragma unroll
+        for (int k = 0; k < C2_PFN_N; ++k) used |= pf_sink[k];
+        asm volatile("" :: "v"(used));
+    }
 #ifdef SURFD_C2_STAMPS
     C2_STAMP(9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1313,6 +1352,9 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
 #endif
     static const int lds_extra = env_int("SURFD_CONV2_LDS_EXTRA", 0);   // developer aid: fewer workgroups per CU (occupancy experiments)
     lds += (size_t)lds_extra;
+    lds = (lds + 255) & ~(size_t)255;
+    A.off_pf = (int)lds;               // landing area of the weight prefetch (256 bytes, never read)
+    lds += 256;
     if (lds > 160 * 1024) return 1;
     A.whf = u->whf + c.whf_off; A.KS16 = c.KS16;
     if (nt2) { A.whf = u->whf2 + c.whf2_off; A.KS16 = c.KS16_2; }
@@ -1377,6 +1419,9 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
 #endif
         lds += (size_t)lds_extra;
+        lds = (lds + 255) & ~(size_t)255;
+        A.off_pf = (int)lds;
+        lds += 256;
     }
     A.part = u->part; A.counters = u->counters;
     A.sat = u->sat;

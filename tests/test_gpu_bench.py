@@ -60,7 +60,9 @@ def test_eight_ranks_over_gloo_on_one_gpu(mode):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, SURFD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    small = ["--steps", "2", "--warmup", "0", "--diffusion-steps", "20", "--resolution", "64", "--no-trace", "--no-e2", "--no-cpu-baseline", "--mode", mode]
+    # 2 shapes per step and rank: eight processes take turns on one device, and the grid-shard mode meets on the host after every
+    # level of every shape (gloo) — with 8 shapes per step that was 5 minutes of context switching inside the full suite
+    small = ["--steps", "2", "--warmup", "0", "--diffusion-steps", "20", "--resolution", "64", "--batch", "2", "--no-trace", "--no-e2", "--no-cpu-baseline", "--mode", mode]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8"] + small
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
@@ -71,10 +73,10 @@ def test_eight_ranks_over_gloo_on_one_gpu(mode):
     assert [p["rank"] for p in pr] == list(range(8)) and all(p["ms_per_step"] > 0 for p in pr)
     if mode == "shape-parallel":
         assert d["scaling"] == "weak" and d["rccl_ranks"] == 8
-        assert d["value"] == pytest.approx(8 * 8 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
+        assert d["value"] == pytest.approx(8 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
         firsts = [p["first_shape_index"] for p in pr]
-        assert firsts == [r * 8 for r in range(8)]                      # step 0: rank r samples the global shapes 8 r ... 8 r + 7
-        assert all(p["decoder_fwd_queries"] >= 2 * 8 * 32 ** 3 for p in pr)
+        assert firsts == [r * 2 for r in range(8)]                      # step 0: rank r samples the global shapes 2 r, 2 r + 1
+        assert all(p["decoder_fwd_queries"] >= 2 * 2 * 32 ** 3 for p in pr)
         assert all(p["startup_s"] > 0 for p in pr)
         ncpu = len(os.sched_getaffinity(0))
         if ncpu >= 16:                                                   # two or more CPUs per rank: every rank is pinned to its own slice
