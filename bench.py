@@ -396,7 +396,7 @@ def committed_traffic():
     collected in their own rocprofv3 --pmc runs as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per the gfx950 note).
     A profile names the kernel sources it was collected with (sha256); if they have changed since, nothing is quoted."""
     import hashlib
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -909,14 +909,19 @@ def grid_shard_main(a, world, rank):
         dec.bind_latents(lat.reshape(B, a.latent))
         for k in range(B):
             if a.shard_path == "native":
+                # adaptive: the exchange buffers follow the fields (largest counts seen so far x 1.5 / 2): one read of the counts per
+                # shape; a shape that does not fit (fields differ by more than that: round 5's first run with buffers sized from the
+                # first step's shapes cut one) is repeated with larger ones INSIDE the timed region, on every rank alike
                 filler.fill_grid_sharded(make_udf_func(dec, lat[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=False,
-                                         capacity=a.shard_capacity, grad_capacity=a.shard_grad_capacity)
+                                         adaptive=not fixed_caps, capacity=a.shard_capacity if fixed_caps else None,
+                                         grad_capacity=a.shard_grad_capacity if fixed_caps else None)
             else:
                 filler.fill_grid(ShardedField(make_udf_func(dec, lat[k], sample=k)), 2 ** 22, out=(udf, grads), stats=True)
                 fwd_pts[0] += sum(filler.last_stats["fwd_per_level"])
         return lat
 
-    if a.shard_path == "native" and (a.shard_capacity <= 0 or a.shard_grad_capacity <= 0):
+    fixed_caps = a.shard_capacity > 0 and a.shard_grad_capacity > 0          # both given on the command line: fixed buffers, no read per shape
+    if a.shard_path == "native" and not fixed_caps:
         # exchange-buffer capacities from the field itself, PER LEVEL: the B untimed shapes of the first step with generous
         # buffers, their device-side counts read once each; every rank sees the same grids, hence the same counts and the same
         # capacities (the collectives' sizes must agree).  Fields differ from shape to shape: twice the largest count seen per
@@ -929,15 +934,11 @@ def grid_shard_main(a, world, rank):
             filler.fill_grid_sharded(make_udf_func(dec, lat0[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=True,
                                      capacity=min(1 << 26, 7 * (N // 2) ** 3), grad_capacity=min(1 << 25, N ** 3))
             seen.append(filler.last_stats)
-        caps, gcap = filler.plan_shard_capacities(seen, world, margin=2.0, grad_margin=4.0)
-        if a.shard_capacity > 0:
-            caps = filler.shard_capacities(a.shard_capacity, gcap)[0]
-        if a.shard_grad_capacity > 0:
-            gcap = filler.shard_capacities(caps, a.shard_grad_capacity)[1]
-        a.shard_capacity, a.shard_grad_capacity = caps, gcap
+        filler._shard_seen = {"fwd_per_level": [max(st["fwd_per_level"][l] for st in seen) for l in range(len(filler.N_levels))],
+                              "grad": max(st["grad"] for st in seen)}
+        filler.plan_shard_capacities([filler._shard_seen], world, margin=1.5, grad_margin=2.0)      # the adaptive fills continue from here
         filler._shard_buf = None
         torch.cuda.empty_cache()
-    shard_caps = filler.shard_capacities(a.shard_capacity, a.shard_grad_capacity) if a.shard_path == "native" else None
     for s in range(a.warmup):
         one_step(s)
     if filler._handle is not None:
@@ -954,12 +955,14 @@ def grid_shard_main(a, world, rank):
     local_ms = (time.perf_counter() - t0) * 1e3
     barrier(world)
     elapsed = time.perf_counter() - t0               # the timed region ends HERE; what follows is measured on the side
+    shard_caps = None
     if a.shard_path == "native":
         tot = filler.totals(reset=True)             # running totals kept on the device by the fills: one read, after the clock
         fwd_pts[0] = float(sum(tot["fwd_per_level"]))
         # capacity check over EVERY shape of the timed region: each commit compared its list with its buffer on the device
         # (counts differ from shape to shape — the last shape's counts say nothing about the others); one read, after the clock
         cut = filler.shard_overflows(reset=True)
+        shard_caps = filler.shard_capacities(a.shard_capacity if fixed_caps else None, a.shard_grad_capacity if fixed_caps else None)
         assert cut == 0, (f"{cut} exchange buffer(s) of the timed region were shorter than their list (capacities {shard_caps}): the grids "
                           f"of this run are incomplete — raise --shard-capacity / --shard-grad-capacity")
     # what one shape hands to the collective (every level's buffer + the gradient buffer; with one rank nothing is exchanged, the
@@ -981,8 +984,9 @@ def grid_shard_main(a, world, rank):
     t1 = time.perf_counter()
     for k in range(B):
         if a.shard_path == "native":
-            filler.fill_grid_sharded(make_udf_func(dec, lat[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=False, capacity=a.shard_capacity,
-                                     grad_capacity=a.shard_grad_capacity)
+            filler.fill_grid_sharded(make_udf_func(dec, lat[k], sample=k), rank=rank, world=world, out=(udf, grads), stats=False,
+                                     adaptive=not fixed_caps, capacity=a.shard_capacity if fixed_caps else None,
+                                     grad_capacity=a.shard_grad_capacity if fixed_caps else None)
         else:
             filler.fill_grid(ShardedField(make_udf_func(dec, lat[k], sample=k)), 2 ** 22, out=(udf, grads), stats=False)
     torch.cuda.synchronize()
@@ -1007,7 +1011,9 @@ def grid_shard_main(a, world, rank):
            "config": {"workload": f"{cfg['name']}; grid-shard mode: reverse loop replicated, every level of every shape's {N}^3 grid split over {world} rank(s) "
                                   "by index range, values returned by ncclAllGather (end point E1)", "mode": "grid-shard", "baseline_config": a.config,
                       "shapes_per_step": B, "resolution": N, "diffusion_steps": T, "decoder_fwd_queries_per_shape": fwd_pts[0] / max(shapes, 1),
-                      "shard_path": a.shard_path, "host_syncs_per_shape": 0 if a.shard_path == "native" else len(filler.N_levels) + 1,
+                      "shard_path": a.shard_path, "host_syncs_per_shape": (0 if fixed_caps else 1) if a.shard_path == "native" else len(filler.N_levels) + 1,
+                      "exchange_capacities": ("fixed (command line)" if fixed_caps else "adaptive: largest counts seen so far x 1.5 (gradient points x 2), one read of the counts per shape, "
+                                              "a shape that does not fit is repeated inside the timed region") if a.shard_path == "native" else None,
                       "exchange_capacity_points": {"per_level": shard_caps[0], "gradients": shard_caps[1]} if a.shard_path == "native" else None,
                       "exchange_bytes_per_shape": bytes_exchanged_per_shape if a.shard_path == "native" else None,
                       "exchange_buffers_cut_in_timed_region": 0 if a.shard_path == "native" else None,

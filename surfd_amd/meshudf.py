@@ -266,8 +266,15 @@ class GridFiller:
             over = [(l, c, cap) for l, (c, cap) in enumerate(zip(self.last_stats["fwd_per_level"], caps)) if c > cap]
             cut = bool(over) or (grads is not None and self.last_stats["grad"] > gcap)
             if adaptive:
-                # a cut level hides how long its children would have been: plan from what was seen, with twice the margin, and go again
-                self.plan_shard_capacities([self.last_stats], world, margin=3.0 if cut else 1.5, grad_margin=4.0 if cut else 2.0)
+                # plan from the largest counts seen on this filler so far (fields differ from shape to shape: following only the
+                # last one would repeat every shape that is larger than its predecessor); a cut level hides how long its children
+                # would have been: twice the margin, and go again
+                seen = getattr(self, "_shard_seen", None)
+                cur = {"fwd_per_level": list(self.last_stats["fwd_per_level"]), "grad": self.last_stats["grad"]}
+                if seen is not None:
+                    cur = {"fwd_per_level": [max(a, b) for a, b in zip(cur["fwd_per_level"], seen["fwd_per_level"])], "grad": max(cur["grad"], seen["grad"])}
+                self._shard_seen = cur
+                self.plan_shard_capacities([cur], world, margin=3.0 if cut else 1.5, grad_margin=4.0 if cut else 2.0)
                 if cut and attempt < 2:
                     self.shard_overflows(reset=True)
                     capacity = grad_capacity = None
