@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--loop-chains", type=int, default=None,
                     help="reverse loops in flight at once, each on its own stream and execution context (MDM.replica); "
                          "default 2 (phased) / 3 (overlap)")
+    ap.add_argument("--loop-driver", choices=["interleaved", "threads"], default="interleaved",
+                    help="phased: the loops of a round driven by one host thread handing graph replays to them in turn (fixed "
+                         "submission order; profiles/r05_loop_experiments.md §9) or by one host thread per loop (through round 4)")
+    ap.add_argument("--loop-chunk", type=int, default=1, help="interleaved driver: graph replays handed to a loop per turn")
     ap.add_argument("--loop-batches", type=int, default=10,
                     help="phased: steps whose latents ride in ONE wide reverse loop (10 x 8 = 80 latents per loop)")
     ap.add_argument("--wide-design-batch", type=int, default=80,
@@ -486,6 +490,15 @@ class Job:
                                            noise_stream=noise, fused=True)
         self.sample_latents = sample_latents
 
+        def sample_round(parts, streams):
+            """all loops of a round from ONE host thread, graph replays handed to the loops in turn (fixed submission order)"""
+            jobs = []
+            for (c, first, n), st in zip(parts, streams):
+                with torch.cuda.stream(st):                   # the loop's inputs are gathered on the loop's own stream
+                    jobs.append({"model": wrapped[c], "shape": (n * B, 1, a.latent), "model_kwargs": loop_kwargs(first, n), "stream": st,
+                                 "noise_stream": noise_bank[first:first + n].permute(1, 0, 2, 3, 4).reshape(T + 1, n * B, 1, a.latent).contiguous()})
+            return diffusion.fused_loops_interleaved(jobs, sampler="ddpm", clip_denoised=False, chunk=a.loop_chunk, wait_current=False)
+
         self.trace = trace if workload == "trace" else None
         trace = self.trace
         self.filler = filler = GridFiller(N)
@@ -521,7 +534,8 @@ class Job:
 
         if schedule == "phased":
             self.pipe = PhasedPipeline(sample_latents, fill_grids, chains=n_chains, max_loop_batches=loop_batches, overlap_blocks=a.overlap_blocks,
-                                       decoder=dec, first_round_batches=a.first_round if a.overlap_blocks else 0)
+                                       decoder=dec, first_round_batches=a.first_round if a.overlap_blocks else 0,
+                                       loops_fn=sample_round if a.loop_driver == "interleaved" else None)
         elif schedule == "overlap":
             self.pipe = BatchPipeline(dec, lambda s, q: sample_latents(s, 1, q), fill_grids, a.decoder_blocks, loop_chains=n_chains)
         else:
@@ -826,9 +840,10 @@ def main():
                    "decoder_precision": a.decoder_precision, "unet_precision": a.unet_precision,
                    "fp16_range_saturations": sat,
                    "schedule": a.schedule, "pipeline": sched,
+                   "loop_driver": (a.loop_driver + (f" (one host thread, {a.loop_chunk} graph replay(s) per loop and turn)" if a.loop_driver == "interleaved" else " (one host thread per loop)")) if a.schedule == "phased" else "n/a",
                    "rounds": meas["rounds"], "rounds_means": "time-sliced rounds inside the timed region (loops of a round, then its grids); 1 = the whole region is one round",
                    "startup_s": meas["startup_s"],
-                   "host_threads_per_rank": {"loop_chains": n_chains, "meshing": (mesh_stats or {}).get("threads", 0), "host_cores": os.cpu_count(), "ranks": world,
+                   "host_threads_per_rank": {"loop_chains": n_chains, "loop_driver_threads": 1 if (a.schedule == "phased" and a.loop_driver == "interleaved") else n_chains, "meshing": (mesh_stats or {}).get("threads", 0), "host_cores": os.cpu_count(), "ranks": world,
                                              "cpus_of_rank_0": _cpu_ranges(PINNED_CPUS) if PINNED_CPUS else "not pinned (one rank)"},
                    "parallelism": f"shape-parallel x{world}, no data-path collective (latents all_gathered after the timed region)"},
         "roofline": {"kernel": kname, "bound": "mfma",

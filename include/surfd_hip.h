@@ -146,6 +146,17 @@ typedef struct {
 int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise,
                       const float *ctx, const int64_t *cls, float *x_out, float *traj,
                       int B, int L, surfd_stream s);
+/* The same loop in three calls, for a host thread that drives several loops (one surfd_unet handle and one stream each) in
+ * turns: begin = the host-synchronous part (embedding rows, coefficient table, state <- noise row 0, the captured iteration),
+ * run = up to `iterations` more graph replays on s (asynchronous; *remaining, nullable, = replays still to launch),
+ * end = x_out <- state once every iteration has been launched (SURFD_ERR_STATE before that).  begin + run(T') + end IS
+ * surfd_sample_loop; noise / ctx / cls / traj must stay alive until the stream has passed end.  The loop they spell is
+ * p_sample_loop_progressive's for-loop (diffusion/gaussian_diffusion.py:682-708) cut at iteration boundaries. */
+int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise,
+                            const float *ctx, const int64_t *cls, float *traj, int B, int L,
+                            surfd_stream s);
+int surfd_sample_loop_run(surfd_unet *u, int iterations, int *remaining, surfd_stream s);
+int surfd_sample_loop_end(surfd_unet *u, float *x_out, surfd_stream s);
 /* single posterior updates on n elements (used by the generic Python loop) */
 int surfd_ddpm_step(const float *x_t, const float *x0, const float *z, float coef1, float coef2,
                     float log_variance, int t_nonzero, int clip_denoised, float *out, int64_t n,

@@ -60,6 +60,9 @@ _SIGS = {
     "surfd_unet_debug_only_op": (C.c_int, [_P, C.c_int]),
     "surfd_unet_debug_run_module": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "surfd_sample_loop": (C.c_int, [_P, C.POINTER(SamplerCfg), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "surfd_sample_loop_begin": (C.c_int, [_P, C.POINTER(SamplerCfg), _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "surfd_sample_loop_run": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P]),
+    "surfd_sample_loop_end": (C.c_int, [_P, _P, _P]),
     "surfd_ddpm_step": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "surfd_ddim_step": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                   C.c_int, _P, C.c_int64, _P]),

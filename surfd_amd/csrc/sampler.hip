@@ -111,9 +111,13 @@ __global__ void loop_advance_kernel(int *step_ptr) { *step_ptr += 1; }
 
 extern "C" {
 
-int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise, const float *ctx,
-                      const int64_t *cls, float *x_out, float *traj, int B, int L, surfd_stream s) {
-    if (!u || !cfg || !noise || !x_out || B < 1 || L < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad argument");
+// A fused loop in three parts (round 5): begin = everything up to the instantiated step graph (embedding rows, coefficient table,
+// state <- noise row 0, counter <- 0), run = n graph replays, end = the state copied out.  surfd_sample_loop is the three in a
+// row; a host thread that interleaves several loops calls begin on each, run in turns, end on each
+// (SpacedDiffusion.fused_loops_interleaved): one deterministic submission order instead of one racing thread per loop.
+int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise, const float *ctx,
+                            const int64_t *cls, float *traj, int B, int L, surfd_stream s) {
+    if (!u || !cfg || !noise || B < 1 || L < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad argument");
     const int T = cfg->num_steps;
     if (T < 1 || !cfg->timestep_map) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad schedule");
     if (cfg->sampler == 0 && (!cfg->coef1 || !cfg->coef2 || !cfg->log_variance))
@@ -211,10 +215,43 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
         HIP_TRY(hipGraphInstantiate(&ls->exec, g, nullptr, nullptr, 0));
         memcpy(ls->key, key, sizeof(key));
     }
-    for (int k = 0; k < T; ++k) HIP_TRY(hipGraphLaunch(ls->exec, st));
-    HIP_TRY(hipMemcpyAsync(x_out, ls->x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    prof_end(PROF_LOOP, prof_ev, st);
+    ls->run_T = T; ls->run_done = 0; ls->run_n = n;
+    ls->prof_ev = prof_ev;
     return SURFD_OK;
+}
+
+int surfd_sample_loop_run(surfd_unet *u, int iterations, int *remaining, surfd_stream s) {
+    if (!u || iterations < 0) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop_run: bad argument");
+    LoopState *ls = unet_loop_state(u);
+    if (!ls->exec || ls->run_T <= 0) SURFD_FAIL(SURFD_ERR_STATE, "surfd_sample_loop_run: call surfd_sample_loop_begin first");
+    hipStream_t st = as_stream(s);
+    const int k = std::min(iterations, ls->run_T - ls->run_done);
+    for (int i = 0; i < k; ++i) HIP_TRY(hipGraphLaunch(ls->exec, st));
+    ls->run_done += k;
+    if (remaining) *remaining = ls->run_T - ls->run_done;
+    return SURFD_OK;
+}
+
+int surfd_sample_loop_end(surfd_unet *u, float *x_out, surfd_stream s) {
+    if (!u || !x_out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop_end: null argument");
+    LoopState *ls = unet_loop_state(u);
+    if (ls->run_T <= 0) SURFD_FAIL(SURFD_ERR_STATE, "surfd_sample_loop_end: no loop is open");
+    if (ls->run_done != ls->run_T)
+        SURFD_FAIL(SURFD_ERR_STATE, "surfd_sample_loop_end: %d of %d iterations have been launched", ls->run_done, ls->run_T);
+    hipStream_t st = as_stream(s);
+    HIP_TRY(hipMemcpyAsync(x_out, ls->x, (size_t)ls->run_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    prof_end(PROF_LOOP, (hipEvent_t)ls->prof_ev, st);
+    ls->run_T = 0; ls->prof_ev = nullptr;
+    return SURFD_OK;
+}
+
+int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise, const float *ctx,
+                      const int64_t *cls, float *x_out, float *traj, int B, int L, surfd_stream s) {
+    if (!x_out) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad argument");
+    int rc = surfd_sample_loop_begin(u, cfg, noise, ctx, cls, traj, B, L, s);
+    if (rc) return rc;
+    if ((rc = surfd_sample_loop_run(u, cfg->num_steps, nullptr, s))) return rc;
+    return surfd_sample_loop_end(u, x_out, s);
 }
 
 // Iterations the fused loop of this handle has finished (the device-side counter the head convolution advances), read over a

@@ -70,6 +70,9 @@ struct LoopState {
     hipGraph_t graph = nullptr;
     hipStream_t cap_stream = nullptr;   // private stream used only to record the graph (the caller's may be the null stream)
     hipStream_t poll_stream = nullptr;  // surfd_unet_loop_progress: reads the loop counter beside the stream the loop runs on
+    int run_T = 0, run_done = 0;        // surfd_sample_loop_begin / _run / _end: iterations of the open loop, launched so far
+    long run_n = 0;                     // floats of its state
+    void *prof_ev = nullptr;            // profiling bracket opened by begin, closed by end
     long key[6] = {0, 0, 0, 0, 0, 0};
 };
 LoopState *unet_loop_state(surfd_unet *u);

@@ -264,8 +264,8 @@ class SpacedDiffusion:
         th_.start()
         return stop, th_
 
-    def _fused_loop(self, mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device,
-                    return_trajectory=False, progress=False):
+    def _fused_inputs(self, mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device, return_trajectory):
+        """Everything surfd_sample_loop(_begin) takes, as device tensors / host tables: -> dict (holds the host tables alive)."""
         B, L = shape[0], shape[-1]
         T = self.num_timesteps
         if noise_stream is None:
@@ -290,12 +290,18 @@ class SpacedDiffusion:
                            fp(tabs["sra"]), fp(tabs["srm1"]), fp(tabs["ab"]), fp(tabs["abp"]))
         out = th.empty(B, *shape[1:], device=device, dtype=th.float32)
         traj = th.empty(T, B, *shape[1:], device=device, dtype=th.float32) if return_trajectory else None
+        return dict(B=B, L=L, T=T, cfg=cfg, tabs=tabs, tmap=tmap, noise=noise_stream, ctx=ctx, cls=cls, out=out, traj=traj)
+
+    def _fused_loop(self, mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device,
+                    return_trajectory=False, progress=False):
+        a = self._fused_inputs(mdm, shape, sampler, noise, noise_stream, clip_denoised, model_kwargs, eta, device, return_trajectory)
+        T, out, traj = a["T"], a["out"], a["traj"]
         Lh, h = mdm._native()
         bar = self._progress_bar(mdm, T) if progress else None
         t0 = time.time()
         try:
-            N.check(Lh.surfd_sample_loop(h, C.byref(cfg), N.ptr(noise_stream), N.ptr(ctx), N.ptr(cls), N.ptr(out), N.ptr(traj),
-                                         B, L, N.stream()))
+            N.check(Lh.surfd_sample_loop(h, C.byref(a["cfg"]), N.ptr(a["noise"]), N.ptr(a["ctx"]), N.ptr(a["cls"]), N.ptr(out), N.ptr(traj),
+                                         a["B"], a["L"], N.stream()))
             if bar is not None:
                 th.cuda.current_stream(device).synchronize()       # the bar ends when the loop has (the reference's loop is synchronous)
         finally:
@@ -307,6 +313,61 @@ class SpacedDiffusion:
         dt = (time.time() - t0) / T
         self.time_con.extend([dt] * T)
         return (out, traj) if return_trajectory else out
+
+    def fused_loops_interleaved(self, jobs, sampler="ddpm", clip_denoised=True, eta=0.0, chunk=1, wait_current=True):
+        """Several fused reverse loops driven by ONE host thread: every loop is opened (surfd_sample_loop_begin:
+        tables, embeddings, the captured iteration), then the thread hands `chunk` iterations at a time to each loop's stream in
+        turn until all have been launched, then closes them.  The submission order is a fixed function of (len(jobs), chunk) —
+        no host threads racing for the driver's queue lock — and each loop's result is the one surfd_sample_loop gives for
+        the same inputs, bit for bit (tests/test_gpu_unet.py).
+
+        jobs: [{"model": MDM (own execution context: `MDM.replica()`), "shape": (B, 1, L), "noise_stream": [T'+1, B, 1, L],
+                "stream": torch.cuda.Stream, "model_kwargs": {...} (optional)}, ...]   ->  [latents [B, 1, L] per job]
+        Every job's stream waits for the current stream first (wait_current=False: the caller has ordered the streams itself);
+        the caller waits on the job streams (or records events) after."""
+        opened = []
+        cur = th.cuda.current_stream()
+        T = self.num_timesteps
+        t0 = time.time()
+        targets = []
+        for j in jobs:                                   # nothing is opened before every job has been checked
+            self._check_cfg_contract(j["model"], j.get("model_kwargs"))
+            mdm = self._native_target(j["model"])
+            if mdm is None:
+                raise TypeError("fused_loops_interleaved: every job needs an MDM on the GPU")
+            if any(mdm is o for o in targets):
+                raise ValueError("fused_loops_interleaved: two jobs share one execution context (use MDM.replica())")
+            targets.append(mdm)
+        for j, mdm in zip(jobs, targets):
+            dev = next(mdm.parameters()).device
+            st = j["stream"]
+            if wait_current:
+                st.wait_stream(cur)
+            with th.cuda.stream(st):
+                a = self._fused_inputs(mdm, tuple(j["shape"]), sampler, j.get("noise"), j.get("noise_stream"), clip_denoised,
+                                       j.get("model_kwargs"), eta, dev, False)
+                Lh, h = mdm._native()
+                N.check(Lh.surfd_sample_loop_begin(h, C.byref(a["cfg"]), N.ptr(a["noise"]), N.ptr(a["ctx"]), N.ptr(a["cls"]), None,
+                                                   a["B"], a["L"], N.stream()))
+            opened.append((mdm, a, st, Lh, h))
+        left = [T] * len(opened)
+        rem = C.c_int(0)
+        while any(left):
+            for q, (mdm, a, st, Lh, h) in enumerate(opened):
+                if left[q]:
+                    with th.cuda.stream(st):
+                        N.check(Lh.surfd_sample_loop_run(h, int(chunk), C.byref(rem), N.stream()))
+                    left[q] = int(rem.value)
+        outs = []
+        for mdm, a, st, Lh, h in opened:
+            with th.cuda.stream(st):
+                N.check(Lh.surfd_sample_loop_end(h, N.ptr(a["out"]), N.stream()))
+                for k in ("noise", "ctx", "cls"):
+                    if a[k] is not None:
+                        a[k].record_stream(st)
+            outs.append(a["out"])
+        self.time_con.extend([(time.time() - t0) / T] * T)
+        return outs
 
     def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               skip_timesteps, init_image, randomize_class, eta, const_noise, noise_stream):

@@ -261,11 +261,16 @@ class PhasedPipeline:
     loop_fn(first_batch, n_batches, chain) -> latents of batches [first_batch, first_batch + n_batches), batch-major;
                                               enqueues ONE reverse loop on the current stream with execution context `chain`
     fill_fn(batch, latents_of_batch) -> None  enqueues that batch's grid evaluation on the current stream
+    loops_fn(parts, streams) -> [latents]     (optional, round 5) enqueues ALL loops of a round from the calling thread:
+                                              parts = [(chain, first_batch, n_batches), ...], loop i on streams[i]
+                                              (SpacedDiffusion.fused_loops_interleaved: one host thread hands graph replays to the
+                                              loops in turn — a fixed submission order).  Without it: one host thread per loop,
+                                              each inside one loop_fn call, racing for the driver's queue.
     """
 
     def __init__(self, loop_fn, fill_fn, chains: int = 2, max_loop_batches: int = 8, overlap_blocks: int = 0, decoder=None,
-                 first_round_batches: int = 0):
-        self.loop_fn, self.fill_fn = loop_fn, fill_fn
+                 first_round_batches: int = 0, loops_fn=None):
+        self.loop_fn, self.fill_fn, self.loops_fn = loop_fn, fill_fn, loops_fn
         self.chains = max(1, int(chains))
         self.max_loop_batches = max(1, int(max_loop_batches))
         self.overlap_blocks = int(overlap_blocks)
@@ -338,7 +343,26 @@ class PhasedPipeline:
                 except BaseException as e:                  # surfaced on the calling thread
                     errors.append(e)
 
-            threads = [threading.Thread(target=worker, args=p, daemon=True) for p in parts]
+            def round_worker():
+                try:
+                    torch.cuda.set_device(dev)
+                    sts = [self.loop_streams[c] for c, _, _ in parts]
+                    if not overlap:
+                        for st in sts:
+                            st.wait_stream(cur)             # time-sliced: the previous round's grids are done before these loops start
+                    xs = self.loops_fn(parts, sts)
+                    for (c, f, n), st, x in zip(parts, sts, xs):
+                        x.record_stream(cur)
+                        ev = torch.cuda.Event(enable_timing=self.record_timeline)
+                        ev.record(st)
+                        results[c] = (f, n, x, ev)
+                except BaseException as e:
+                    errors.append(e)
+
+            if self.loops_fn is not None:
+                threads = [threading.Thread(target=round_worker, daemon=True)]
+            else:
+                threads = [threading.Thread(target=worker, args=p, daemon=True) for p in parts]
             for t in threads:
                 t.start()
             return threads, results, errors

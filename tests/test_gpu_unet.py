@@ -479,6 +479,58 @@ def test_range_guard_on_the_denoiser(capsys):
         model.set_precision("f16x2")
 
 
+def test_interleaved_loops_match_separate_loops():
+    """several loops driven by ONE host thread (surfd_sample_loop_begin / _run / _end, `chunk` graph replays per
+    loop in turn) give, loop for loop, the bits of one surfd_sample_loop call each — latency form and wide form, conditioned and
+    not, any chunk; and the three calls refuse to be used out of order."""
+    import ctypes as C
+    from surfd_amd import _native as N
+    model, _, _ = _model("no_cond")
+    _, dd, _ = _model("no_cond", "ddim20")
+    chains = [model, model.replica(), model.replica()]
+    streams = [torch.cuda.Stream() for _ in chains]
+    try:
+        for wide, widths in ((0, (8, 3, 5)), (40, (40, 40, 27))):
+            for m in chains:
+                m.set_wide(wide)
+            noise = [synth.synth_noise_batch(20, 100 * q, w, 32).cuda() for q, w in enumerate(widths)]
+            ref = [dd.p_sample_loop(chains[q], (w, 1, 32), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise[q], fused=True).clone()
+                   for q, w in enumerate(widths)]
+            torch.cuda.synchronize()
+            for chunk in (1, 3, 20, 64):
+                jobs = [{"model": chains[q], "shape": (w, 1, 32), "noise_stream": noise[q], "stream": streams[q], "model_kwargs": {"y": {}}}
+                        for q, w in enumerate(widths)]
+                n0 = len(dd.time_con)
+                outs = dd.fused_loops_interleaved(jobs, sampler="ddpm", clip_denoised=False, chunk=chunk)
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(ref, outs)), (wide, chunk)
+                assert len(dd.time_con) == n0 + 20
+        with pytest.raises(ValueError):
+            dd.fused_loops_interleaved([{"model": model, "shape": (2, 1, 32), "noise_stream": noise[0][:, :2].contiguous(), "stream": streams[q]} for q in range(2)])
+    finally:
+        for m in chains:
+            m.set_wide(0)
+    # protocol: run / end need an open loop; end needs every iteration launched
+    fresh = model.replica()
+    Lh, h = fresh._native()
+    out = torch.empty(2, 1, 32, device="cuda")
+    rem = C.c_int(0)
+    for call in (lambda: Lh.surfd_sample_loop_run(h, 1, C.byref(rem), N.stream()), lambda: Lh.surfd_sample_loop_end(h, N.ptr(out), N.stream())):
+        with pytest.raises(RuntimeError):
+            N.check(call())
+    a = dd._fused_inputs(fresh, (2, 1, 32), "ddpm", None, synth.synth_noise_batch(20, 0, 2, 32).cuda(), False, {"y": {}}, 0.0, torch.device("cuda"), False)
+    N.check(Lh.surfd_sample_loop_begin(h, C.byref(a["cfg"]), N.ptr(a["noise"]), None, None, None, 2, 32, N.stream()))
+    N.check(Lh.surfd_sample_loop_run(h, 7, C.byref(rem), N.stream()))
+    assert rem.value == 13
+    with pytest.raises(RuntimeError, match="7 of 20"):
+        N.check(Lh.surfd_sample_loop_end(h, N.ptr(out), N.stream()))
+    N.check(Lh.surfd_sample_loop_run(h, 1000, C.byref(rem), N.stream()))          # clipped to what is left
+    assert rem.value == 0
+    N.check(Lh.surfd_sample_loop_end(h, N.ptr(out), N.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, dd.p_sample_loop(model, (2, 1, 32), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=a["noise"], fused=True))
+
+
 def test_cached_loop_graph_survives_workspace_growth():
     """the cached loop graph bakes workspace / embedding-table pointers in; a larger-B call in
     between reallocates them.  The loop must re-capture, not replay against freed memory."""
@@ -665,6 +717,24 @@ def test_phased_pipeline_matches_sequential(wide_model):
     for key in seq:
         for a, b in zip(seq[key], ovl[key]):
             assert torch.equal(a, b), key
+    # round 5: the loops of a round driven by ONE host thread (graph replays handed to the loops in turn) — both schedules, same bits
+    def loops(parts, streams):
+        jobs = []
+        for (c, first, n), st in zip(parts, streams):
+            with torch.cuda.stream(st):
+                jobs.append({"model": chains[c], "shape": (n * B, 1, 32), "stream": st, "model_kwargs": {"y": {}},
+                             "noise_stream": bank[first:first + n].permute(1, 0, 2, 3, 4).reshape(21, n * B, 1, 32).contiguous()})
+        return dd.fused_loops_interleaved(jobs, sampler="ddim", clip_denoised=False, chunk=2, wait_current=False)
+
+    for kw in ({}, {"overlap_blocks": 96, "decoder": dec, "first_round_batches": 1}):
+        one = {}
+        pipe = PhasedPipeline(loop, make_fill(one), chains=2, max_loop_batches=2, loops_fn=loops, **kw)
+        pipe.run(nb)
+        torch.cuda.synchronize()
+        assert set(one) == set(seq)
+        for key in seq:
+            for a, b in zip(seq[key], one[key]):
+                assert torch.equal(a, b), (key, kw.keys())
     with pytest.raises(ValueError):
         PhasedPipeline(loop, make_fill({}), overlap_blocks=96)                    # needs the decoder it sizes
 
