@@ -118,6 +118,7 @@ extern "C" {
 int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise, const float *ctx,
                             const int64_t *cls, float *traj, int B, int L, surfd_stream s) {
     if (!u || !cfg || !noise || B < 1 || L < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad argument");
+    unet_loop_state(u)->run_T = 0;             // a begin that fails leaves no loop open (run / end then report SURFD_ERR_STATE)
     const int T = cfg->num_steps;
     if (T < 1 || !cfg->timestep_map) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad schedule");
     if (cfg->sampler == 0 && (!cfg->coef1 || !cfg->coef2 || !cfg->log_variance))

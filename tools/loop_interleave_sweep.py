@@ -4,7 +4,7 @@ PhasedPipeline did through round 4) or (b) by ONE host thread that hands `chunk`
 turn (SpacedDiffusion.fused_loops_interleaved over surfd_sample_loop_begin / _run / _end).  For (K, width) in 2 x 80, 3 x 53,
 4 x 40: `reps` consecutive timed runs of each driver, in us per (evaluation, latent), and whether the interleaved results equal
 the threaded ones bit for bit.  One JSON line on stdout.
-python tools/loop_interleave_sweep.py [T steps per loop] [reps] [L]"""
+python tools/loop_interleave_sweep.py [T steps per loop] [reps] [L]        (CONFIGS=2x80,4x80 CHUNKS=1 DESIGN=80 to change the sweep)"""
 import json, os, sys, threading, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,14 +14,15 @@ from surfd_amd.diffusion import create_gaussian_diffusion
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-CONFIGS = [(2, 80), (3, 53), (4, 40)]
+CONFIGS = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("CONFIGS", "2x80,3x53,4x40").split(",")]      # loops x width
 CHUNKS = [int(c) for c in os.environ.get("CHUNKS", "1,4").split(",")]
 args = types.SimpleNamespace(cond_mode="no_cond", arch="OpenUNet", num_actions=9, dataset="d", noise_schedule="cosine", sigma_small=True, clip_value=1.0)
 model, _ = create_model_and_diffusion(args)
 diff = create_gaussian_diffusion(args, f"ddim{T}")
 load_model_wo_clip(model, synth.synth_unet_state_dict()); model.to("cuda"); model.eval()
-chains = [model] + [model.replica() for _ in range(3)]
-streams = [torch.cuda.Stream() for _ in range(4)]
+KMAX = max(k for k, _ in CONFIGS)
+chains = [model] + [model.replica() for _ in range(KMAX - 1)]
+streams = [torch.cuda.Stream() for _ in range(KMAX)]
 dev = torch.cuda.current_device()
 
 
@@ -53,7 +54,7 @@ def timed(fn):
 res = {"lib": os.path.basename(os.environ.get("SURFD_LIB", "default")), "T": T, "L": L, "reps": REPS, "unit": "us per (evaluation, latent)", "configs": {}}
 for K, width in CONFIGS:
     for m in chains[:K]:
-        m.set_wide(width)
+        m.set_wide(int(os.environ.get("DESIGN", width)))
     noise = [synth.synth_noise_batch(diff.num_timesteps, q * width, width, L).cuda() for q in range(K)]
     row = {}
     drivers = [("threads", lambda: threaded(K, width, noise))] + [(f"one_thread_chunk{c}", (lambda c=c: interleaved(K, width, noise, c))) for c in CHUNKS]
@@ -71,6 +72,7 @@ for K, width in CONFIGS:
             row[name + "_bit_equal_to_threads"] = all(torch.equal(a, b) for a, b in zip(ref, outs))
     res["configs"][f"{K}x{width}"] = row
 res["saturation"] = int(model.saturation_count())
-base = max(res["configs"]["2x80"]["threads"])
-res["within_5pct_of_2x80_threads"] = {k: {n: max(v) <= 1.05 * base for n, v in r.items() if isinstance(v, list)} for k, r in res["configs"].items()}
+if "2x80" in res["configs"]:
+    base = max(res["configs"]["2x80"]["threads"])
+    res["within_5pct_of_2x80_threads"] = {k: {n: max(v) <= 1.05 * base for n, v in r.items() if isinstance(v, list)} for k, r in res["configs"].items()}
 print(json.dumps(res), flush=True)
