@@ -267,6 +267,14 @@ __device__ __forceinline__ void lds_bar() {
 #ifndef SURFD_C2_PFN
 #define SURFD_C2_PFN 1
 #endif
+// SURFD_C2_PFN_FORMS: 0 (default) = only the lean instantiations (three workgroups per CU; every wide launch of an L = 32 model
+// and the <= 32-position levels of an L = 64 model) carry the request; 1 = every instantiation.  With the request compiled into the
+// VEC = 16 wide kernel (the 64-position level of the L = 64 models: C4 / C5) that kernel's results were no longer bit-stable from
+// run to run and left the 1e-4 bound (one denoiser evaluation at 80 x 64: 1e-3; whole samples of workgroups beyond the first
+// 22 samples' worth) — even with the request pointed at the launch's own first weight line.  profiles/r05_loop_experiments.md §8.
+#ifndef SURFD_C2_PFN_FORMS
+#define SURFD_C2_PFN_FORMS 0
+#endif
 #ifndef SURFD_C2_PFN_N
 #define SURFD_C2_PFN_N 1
 #endif
@@ -324,9 +332,22 @@ __device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, un
                      : "=&s"(keep) : "v"(w + off[k]), "s"(dst) : "memory");
         sink[k] = 0u;
     }
+#elif defined(SURFD_C2_PFN_NOLOAD)      // developer aid: the index arithmetic without the memory request
+#pragma unroll
+    for (int k = 0; k < C2_PFN_N; ++k) sink[k] = (unsigned)off[k] ^ (unsigned)(size_t)w;
 #else
 #pragma unroll
     for (int k = 0; k < C2_PFN_N; ++k) sink[k] = *reinterpret_cast<const unsigned *>(w + off[k]);
+#endif
+#if defined(SURFD_C2_PFN_EARLYUSE)      // developer aid: the requested word is awaited right here instead of at the kernel's end
+    {
+        unsigned used = 0u;
+#pragma unroll
+        for (int k = 0; k < C2_PFN_N; ++k) used |= sink[k];
+        asm volatile("" :: "v"(used));
+#pragma unroll
+        for (int k = 0; k < C2_PFN_N; ++k) sink[k] = 0u;
+    }
 #endif
 #else
 #pragma unroll
@@ -552,7 +573,11 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #pragma unroll
     for (int d = 0; d < C2_D; ++d) load_group(ring[d], cur.base, cur.it_beg + d * C2_U, cur.it_end - 1);
     unsigned pf_sink[C2_PFN_N];
-    c2_prefetch_next(A, tid, pf_sink, (unsigned)(size_t)(lds_raw + A.off_pf));     // the next convolution's weights, towards this XCD's L2
+    if constexpr (SURFD_C2_PFN_FORMS || LEAN) c2_prefetch_next(A, tid, pf_sink, (unsigned)(size_t)(lds_raw + A.off_pf));     // the next convolution's weights, towards this XCD's L2
+    else {
+#pragma unroll
+        for (int k = 0; k < C2_PFN_N; ++k) pf_sink[k] = 0u;
+    }
 
     // ---- epilogue operands (bias + per-(step, sample) embedding + residual), requested now, used at the end ----
     // kept as three separate register sets and only combined in the epilogue: combining them here would put a

@@ -5,8 +5,11 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05prof; mkdir -p $O
+# PMC_ONLY=1: only the counter passes (after a kernel-source change that leaves the timings of the committed runs valid)
+if [ -z "${PMC_ONLY:-}" ]; then
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-trace --no-e2 --no-strict --no-trace-e2 > $O/bench_under_rocprof.json 2> $O/kt.log
+fi
 SHORT="python bench.py --steps 20 --warmup 0 --diffusion-steps 20 --no-cpu-baseline --no-trace --no-e2 --no-strict --no-trace-e2"      # the driver's 20 steps (loops of 80 latents, all grids), 20 instead of 1000 loop iterations
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- $SHORT > $O/pmc_fetch.json 2> $O/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- $SHORT > $O/pmc_write.json 2> $O/pmc_write.log
