@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds differently compiled copies of libsurfd_hip.so for A/B timing on the GPU box (selected with SURFD_LIB=...):
     python tools/build_variants.py name=decoder.hip:-DFLAG[,-DFLAG2] [name2=file@gitrev] ...
-`file:-Dflags` recompiles that one source with extra flags; `file@rev` takes the source text from a git revision.
+`file:-Dflags` recompiles that one source with extra flags; `file@rev` takes the source text from a git revision;
+`file+path[:-Dflags]` takes it from another file (an experiment that is not to touch the tree's source).
 Every other object is shared with the regular build.  Output: surfd_amd/lib/variants/libsurfd_hip_<name>.so"""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,8 +14,12 @@ out_dir = os.path.join(B.LIBDIR, "variants")
 os.makedirs(out_dir, exist_ok=True)
 for spec in sys.argv[1:]:
     name, rest = spec.split("=", 1)
-    flags, rev = [], None
-    if "@" in rest:
+    flags, rev, alt = [], None, None
+    if "+" in rest:
+        src_name, tail = rest.split("+", 1)
+        alt, _, fl = tail.partition(":")
+        flags = fl.split(",") if fl else []
+    elif "@" in rest:
         src_name, rev = rest.split("@", 1)
     elif ":" in rest:
         src_name, fl = rest.split(":", 1)
@@ -23,8 +28,8 @@ for spec in sys.argv[1:]:
         src_name = rest
     src = os.path.join(B.CSRC, src_name)
     tmp = None
-    if rev:
-        text = subprocess.check_output(["git", "show", f"{rev}:surfd_amd/csrc/{src_name}"], cwd=ROOT, text=True)
+    if rev or alt:
+        text = open(alt).read() if alt else subprocess.check_output(["git", "show", f"{rev}:surfd_amd/csrc/{src_name}"], cwd=ROOT, text=True)
         tmp = os.path.join(B.CSRC, f"_variant_{name}_{src_name}")       # next to its headers
         open(tmp, "w").write(text)
         src = tmp
