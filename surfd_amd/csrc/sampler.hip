@@ -118,7 +118,12 @@ extern "C" {
 int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise, const float *ctx,
                             const int64_t *cls, float *traj, int B, int L, surfd_stream s) {
     if (!u || !cfg || !noise || B < 1 || L < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad argument");
-    unet_loop_state(u)->run_T = 0;             // a begin that fails leaves no loop open (run / end then report SURFD_ERR_STATE)
+    {   // a begin that fails leaves no loop open (run / end then report SURFD_ERR_STATE); the profiling bracket of a loop that was
+        // opened and never closed is dropped
+        LoopState *open = unet_loop_state(u);
+        open->run_T = 0;
+        if (open->prof_ev) { (void)hipEventDestroy((hipEvent_t)open->prof_ev); open->prof_ev = nullptr; }
+    }
     const int T = cfg->num_steps;
     if (T < 1 || !cfg->timestep_map) SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: bad schedule");
     if (cfg->sampler == 0 && (!cfg->coef1 || !cfg->coef2 || !cfg->log_variance))
@@ -127,7 +132,11 @@ int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const f
         SURFD_FAIL(SURFD_ERR_ARG, "surfd_sample_loop: DDIM tables missing");
     hipStream_t st = as_stream(s);
     const long n = (long)B * L;
-    hipEvent_t prof_ev = prof_begin(PROF_LOOP, st);
+    struct ProfBracket {                       // closed by surfd_sample_loop_end; destroyed here if this call fails
+        hipEvent_t ev;
+        bool handed_over = false;
+        ~ProfBracket() { if (ev && !handed_over) (void)hipEventDestroy(ev); }
+    } prof{prof_begin(PROF_LOOP, st)};
     // every timestep-only quantity of the denoiser for all T' iterations at once: loop
     // iteration k runs original timestep timestep_map[T'-1-k] for every sample
     // (one row per step when nothing but t enters the embedding, else one per (step, sample): T' x B x 14112 floats)
@@ -217,7 +226,8 @@ int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const f
         memcpy(ls->key, key, sizeof(key));
     }
     ls->run_T = T; ls->run_done = 0; ls->run_n = n;
-    ls->prof_ev = prof_ev;
+    ls->prof_ev = prof.ev;
+    prof.handed_over = true;
     return SURFD_OK;
 }
 
