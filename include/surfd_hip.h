@@ -150,7 +150,9 @@ int surfd_sample_loop(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *
  * turns: begin = the host-synchronous part (embedding rows, coefficient table, state <- noise row 0, the captured iteration),
  * run = up to `iterations` more graph replays on s (asynchronous; *remaining, nullable, = replays still to launch),
  * end = x_out <- state once every iteration has been launched (SURFD_ERR_STATE before that).  begin + run(T') + end IS
- * surfd_sample_loop; noise / ctx / cls / traj must stay alive until the stream has passed end.  The loop they spell is
+ * surfd_sample_loop; noise / ctx / cls / traj must stay alive until the stream has passed end.  One loop per handle at a time
+ * (a second begin on the same handle abandons the first; several loops = several handles, all three calls of a handle from one
+ * host thread or externally serialised); a begin that fails leaves no loop open.  The loop they spell is
  * p_sample_loop_progressive's for-loop (diffusion/gaussian_diffusion.py:682-708) cut at iteration boundaries. */
 int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const float *noise,
                             const float *ctx, const int64_t *cls, float *traj, int B, int L,
