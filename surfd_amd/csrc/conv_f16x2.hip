@@ -59,7 +59,12 @@ struct Conv2Args {
     int nseg;
     const _Float16 *whf;   // [ntiles][KS16][2 planes][64 lanes][8]
     int KS16;
+#if defined(SURFD_C2_PROBE) || defined(SURFD_C2_DBG_POISON)      // developer builds: the two fields the kernel never reads carry the probe buffer / LDS size (the struct fills its eight lines)
+    unsigned long long *probe;   // [workgroup][8] phase checksums of this launch (tools/probe_phases.py) or null
+#define C2_LDS_BYTES plane
+#else
     const float *sc;       // {SC, 1/SC} on the device (weight preparation); the kernel takes 1/SC by value:
+#endif
     float inv_sc;          // a dependent scalar load in front of everything else cost ~1 us per workgroup
     const float *bias;     // [Cout]
     const float *emb;      // emb[b * emb_bstride + co] or null
@@ -97,6 +102,9 @@ struct Conv2Args {
 
 #ifndef SURFD_C2_EPI_LATE
 #define SURFD_C2_EPI_LATE 1
+#endif
+#ifndef SURFD_C2_BPIPE
+#define SURFD_C2_BPIPE 0
 #endif
 #ifndef SURFD_C2_LAT_D
 #define SURFD_C2_LAT_D 2
@@ -355,6 +363,109 @@ __device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, un
 #endif
 }
 
+// Developer aids of the round-6 hunt for the "second workgroup on a CU" instability (profiles/r06_conv2_instability.md).
+// -DSURFD_C2_PROBE: every workgroup adds order-sensitive checksums of its phases — raw operand, GroupNorm mean / scale, staged
+// values, the slab read back from LDS, weight fragments consumed, accumulators, epilogue operands, stored values — to eight
+// 64-bit words of a probe buffer (SURFD_CONV2_PROBE_PTR = device address, indexed by conv op id); two evaluations of the
+// same input are compared word by word: the first (launch, phase, workgroup) that differs names where the bits change.
+#ifdef SURFD_C2_PROBE
+#define C2_PROBE_ADD(slot, h) do { if (A.probe) atomicAdd(A.probe + (size_t)blockIdx.x * 8 + (slot), (unsigned long long)(h)); } while (0)
+#else
+#define C2_PROBE_ADD(slot, h) do { } while (0)
+#endif
+// -DSURFD_C2_DBG_POISON=1 (zeros) / =2 (0x7fc00000, a quiet NaN): the first instructions of every wave write the pattern to
+// v1..v255 and s4..s99 (v0 = thread id, s[0:1] = kernel arguments, s2 = workgroup id are live) and the whole dynamic LDS
+// allocation — a value read before it is written can no longer be what another wave left behind.
+#if defined(SURFD_C2_DBG_POISON) && SURFD_C2_DBG_POISON
+// (v160..v167 of the lean form and v248..v255 of the others stay out: the compiler needs a register across the statement for its
+//  SGPR spill lanes; s32 / s33 are reserved)
+template <bool HI>
+__device__ __forceinline__ void c2_poison_registers() {
+    constexpr unsigned pat = SURFD_C2_DBG_POISON == 2 ? 0x7fc00000u : 0u;
+    if constexpr (HI) asm volatile(
+        "v_mov_b32 v160, %0\n\tv_mov_b32 v161, %0\n\tv_mov_b32 v162, %0\n\tv_mov_b32 v163, %0\n\tv_mov_b32 v164, %0\n\tv_mov_b32 v165, %0\n\t"
+        "v_mov_b32 v166, %0\n\tv_mov_b32 v167, %0\n\tv_mov_b32 v168, %0\n\tv_mov_b32 v169, %0\n\tv_mov_b32 v170, %0\n\tv_mov_b32 v171, %0\n\t"
+        "v_mov_b32 v172, %0\n\tv_mov_b32 v173, %0\n\tv_mov_b32 v174, %0\n\tv_mov_b32 v175, %0\n\tv_mov_b32 v176, %0\n\tv_mov_b32 v177, %0\n\t"
+        "v_mov_b32 v178, %0\n\tv_mov_b32 v179, %0\n\tv_mov_b32 v180, %0\n\tv_mov_b32 v181, %0\n\tv_mov_b32 v182, %0\n\tv_mov_b32 v183, %0\n\t"
+        "v_mov_b32 v184, %0\n\tv_mov_b32 v185, %0\n\tv_mov_b32 v186, %0\n\tv_mov_b32 v187, %0\n\tv_mov_b32 v188, %0\n\tv_mov_b32 v189, %0\n\t"
+        "v_mov_b32 v190, %0\n\tv_mov_b32 v191, %0\n\tv_mov_b32 v192, %0\n\tv_mov_b32 v193, %0\n\tv_mov_b32 v194, %0\n\tv_mov_b32 v195, %0\n\t"
+        "v_mov_b32 v196, %0\n\tv_mov_b32 v197, %0\n\tv_mov_b32 v198, %0\n\tv_mov_b32 v199, %0\n\tv_mov_b32 v200, %0\n\tv_mov_b32 v201, %0\n\t"
+        "v_mov_b32 v202, %0\n\tv_mov_b32 v203, %0\n\tv_mov_b32 v204, %0\n\tv_mov_b32 v205, %0\n\tv_mov_b32 v206, %0\n\tv_mov_b32 v207, %0\n\t"
+        "v_mov_b32 v208, %0\n\tv_mov_b32 v209, %0\n\tv_mov_b32 v210, %0\n\tv_mov_b32 v211, %0\n\tv_mov_b32 v212, %0\n\tv_mov_b32 v213, %0\n\t"
+        "v_mov_b32 v214, %0\n\tv_mov_b32 v215, %0\n\tv_mov_b32 v216, %0\n\tv_mov_b32 v217, %0\n\tv_mov_b32 v218, %0\n\tv_mov_b32 v219, %0\n\t"
+        "v_mov_b32 v220, %0\n\tv_mov_b32 v221, %0\n\tv_mov_b32 v222, %0\n\tv_mov_b32 v223, %0\n\tv_mov_b32 v224, %0\n\tv_mov_b32 v225, %0\n\t"
+        "v_mov_b32 v226, %0\n\tv_mov_b32 v227, %0\n\tv_mov_b32 v228, %0\n\tv_mov_b32 v229, %0\n\tv_mov_b32 v230, %0\n\tv_mov_b32 v231, %0\n\t"
+        "v_mov_b32 v232, %0\n\tv_mov_b32 v233, %0\n\tv_mov_b32 v234, %0\n\tv_mov_b32 v235, %0\n\tv_mov_b32 v236, %0\n\tv_mov_b32 v237, %0\n\t"
+        "v_mov_b32 v238, %0\n\tv_mov_b32 v239, %0\n\tv_mov_b32 v240, %0\n\tv_mov_b32 v241, %0\n\tv_mov_b32 v242, %0\n\tv_mov_b32 v243, %0\n\t"
+        "v_mov_b32 v244, %0\n\tv_mov_b32 v245, %0\n\tv_mov_b32 v246, %0\n\tv_mov_b32 v247, %0\n\t"
+        "s_nop 0"
+        :: "s"(pat)
+        :
+          "v160","v161","v162","v163","v164","v165","v166","v167","v168","v169","v170","v171","v172","v173","v174","v175","v176","v177","v178","v179","v180","v181","v182","v183",
+          "v184","v185","v186","v187","v188","v189","v190","v191","v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207",
+          "v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231",
+          "v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247");
+    asm volatile(
+        "v_mov_b32 v1, %0\n\tv_mov_b32 v2, %0\n\tv_mov_b32 v3, %0\n\tv_mov_b32 v4, %0\n\tv_mov_b32 v5, %0\n\tv_mov_b32 v6, %0\n\t"
+        "v_mov_b32 v7, %0\n\tv_mov_b32 v8, %0\n\tv_mov_b32 v9, %0\n\tv_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\t"
+        "v_mov_b32 v13, %0\n\tv_mov_b32 v14, %0\n\tv_mov_b32 v15, %0\n\tv_mov_b32 v16, %0\n\tv_mov_b32 v17, %0\n\tv_mov_b32 v18, %0\n\t"
+        "v_mov_b32 v19, %0\n\tv_mov_b32 v20, %0\n\tv_mov_b32 v21, %0\n\tv_mov_b32 v22, %0\n\tv_mov_b32 v23, %0\n\tv_mov_b32 v24, %0\n\t"
+        "v_mov_b32 v25, %0\n\tv_mov_b32 v26, %0\n\tv_mov_b32 v27, %0\n\tv_mov_b32 v28, %0\n\tv_mov_b32 v29, %0\n\tv_mov_b32 v30, %0\n\t"
+        "v_mov_b32 v31, %0\n\tv_mov_b32 v32, %0\n\tv_mov_b32 v33, %0\n\tv_mov_b32 v34, %0\n\tv_mov_b32 v35, %0\n\tv_mov_b32 v36, %0\n\t"
+        "v_mov_b32 v37, %0\n\tv_mov_b32 v38, %0\n\tv_mov_b32 v39, %0\n\tv_mov_b32 v40, %0\n\tv_mov_b32 v41, %0\n\tv_mov_b32 v42, %0\n\t"
+        "v_mov_b32 v43, %0\n\tv_mov_b32 v44, %0\n\tv_mov_b32 v45, %0\n\tv_mov_b32 v46, %0\n\tv_mov_b32 v47, %0\n\tv_mov_b32 v48, %0\n\t"
+        "v_mov_b32 v49, %0\n\tv_mov_b32 v50, %0\n\tv_mov_b32 v51, %0\n\tv_mov_b32 v52, %0\n\tv_mov_b32 v53, %0\n\tv_mov_b32 v54, %0\n\t"
+        "v_mov_b32 v55, %0\n\tv_mov_b32 v56, %0\n\tv_mov_b32 v57, %0\n\tv_mov_b32 v58, %0\n\tv_mov_b32 v59, %0\n\tv_mov_b32 v60, %0\n\t"
+        "v_mov_b32 v61, %0\n\tv_mov_b32 v62, %0\n\tv_mov_b32 v63, %0\n\tv_mov_b32 v64, %0\n\tv_mov_b32 v65, %0\n\tv_mov_b32 v66, %0\n\t"
+        "v_mov_b32 v67, %0\n\tv_mov_b32 v68, %0\n\tv_mov_b32 v69, %0\n\tv_mov_b32 v70, %0\n\tv_mov_b32 v71, %0\n\tv_mov_b32 v72, %0\n\t"
+        "v_mov_b32 v73, %0\n\tv_mov_b32 v74, %0\n\tv_mov_b32 v75, %0\n\tv_mov_b32 v76, %0\n\tv_mov_b32 v77, %0\n\tv_mov_b32 v78, %0\n\t"
+        "v_mov_b32 v79, %0\n\tv_mov_b32 v80, %0\n\tv_mov_b32 v81, %0\n\tv_mov_b32 v82, %0\n\tv_mov_b32 v83, %0\n\tv_mov_b32 v84, %0\n\t"
+        "v_mov_b32 v85, %0\n\tv_mov_b32 v86, %0\n\tv_mov_b32 v87, %0\n\tv_mov_b32 v88, %0\n\tv_mov_b32 v89, %0\n\tv_mov_b32 v90, %0\n\t"
+        "v_mov_b32 v91, %0\n\tv_mov_b32 v92, %0\n\tv_mov_b32 v93, %0\n\tv_mov_b32 v94, %0\n\tv_mov_b32 v95, %0\n\tv_mov_b32 v96, %0\n\t"
+        "v_mov_b32 v97, %0\n\tv_mov_b32 v98, %0\n\tv_mov_b32 v99, %0\n\tv_mov_b32 v100, %0\n\tv_mov_b32 v101, %0\n\tv_mov_b32 v102, %0\n\t"
+        "v_mov_b32 v103, %0\n\tv_mov_b32 v104, %0\n\tv_mov_b32 v105, %0\n\tv_mov_b32 v106, %0\n\tv_mov_b32 v107, %0\n\tv_mov_b32 v108, %0\n\t"
+        "v_mov_b32 v109, %0\n\tv_mov_b32 v110, %0\n\tv_mov_b32 v111, %0\n\tv_mov_b32 v112, %0\n\tv_mov_b32 v113, %0\n\tv_mov_b32 v114, %0\n\t"
+        "v_mov_b32 v115, %0\n\tv_mov_b32 v116, %0\n\tv_mov_b32 v117, %0\n\tv_mov_b32 v118, %0\n\tv_mov_b32 v119, %0\n\tv_mov_b32 v120, %0\n\t"
+        "v_mov_b32 v121, %0\n\tv_mov_b32 v122, %0\n\tv_mov_b32 v123, %0\n\tv_mov_b32 v124, %0\n\tv_mov_b32 v125, %0\n\tv_mov_b32 v126, %0\n\t"
+        "v_mov_b32 v127, %0\n\tv_mov_b32 v128, %0\n\tv_mov_b32 v129, %0\n\tv_mov_b32 v130, %0\n\tv_mov_b32 v131, %0\n\tv_mov_b32 v132, %0\n\t"
+        "v_mov_b32 v133, %0\n\tv_mov_b32 v134, %0\n\tv_mov_b32 v135, %0\n\tv_mov_b32 v136, %0\n\tv_mov_b32 v137, %0\n\tv_mov_b32 v138, %0\n\t"
+        "v_mov_b32 v139, %0\n\tv_mov_b32 v140, %0\n\tv_mov_b32 v141, %0\n\tv_mov_b32 v142, %0\n\tv_mov_b32 v143, %0\n\tv_mov_b32 v144, %0\n\t"
+        "v_mov_b32 v145, %0\n\tv_mov_b32 v146, %0\n\tv_mov_b32 v147, %0\n\tv_mov_b32 v148, %0\n\tv_mov_b32 v149, %0\n\tv_mov_b32 v150, %0\n\t"
+        "v_mov_b32 v151, %0\n\tv_mov_b32 v152, %0\n\tv_mov_b32 v153, %0\n\tv_mov_b32 v154, %0\n\tv_mov_b32 v155, %0\n\tv_mov_b32 v156, %0\n\t"
+        "v_mov_b32 v157, %0\n\tv_mov_b32 v158, %0\n\tv_mov_b32 v159, %0\n\t"
+        "s_mov_b32 s4, %0\n\ts_mov_b32 s5, %0\n\ts_mov_b32 s6, %0\n\ts_mov_b32 s7, %0\n\ts_mov_b32 s8, %0\n\ts_mov_b32 s9, %0\n\t"
+        "s_mov_b32 s10, %0\n\ts_mov_b32 s11, %0\n\ts_mov_b32 s12, %0\n\ts_mov_b32 s13, %0\n\ts_mov_b32 s14, %0\n\ts_mov_b32 s15, %0\n\t"
+        "s_mov_b32 s16, %0\n\ts_mov_b32 s17, %0\n\ts_mov_b32 s18, %0\n\ts_mov_b32 s19, %0\n\ts_mov_b32 s20, %0\n\ts_mov_b32 s21, %0\n\t"
+        "s_mov_b32 s22, %0\n\ts_mov_b32 s23, %0\n\ts_mov_b32 s24, %0\n\ts_mov_b32 s25, %0\n\ts_mov_b32 s26, %0\n\ts_mov_b32 s27, %0\n\t"
+        "s_mov_b32 s28, %0\n\ts_mov_b32 s29, %0\n\ts_mov_b32 s30, %0\n\ts_mov_b32 s31, %0\n\ts_mov_b32 s34, %0\n\ts_mov_b32 s35, %0\n\t"
+        "s_mov_b32 s36, %0\n\ts_mov_b32 s37, %0\n\ts_mov_b32 s38, %0\n\ts_mov_b32 s39, %0\n\ts_mov_b32 s40, %0\n\ts_mov_b32 s41, %0\n\t"
+        "s_mov_b32 s42, %0\n\ts_mov_b32 s43, %0\n\ts_mov_b32 s44, %0\n\ts_mov_b32 s45, %0\n\ts_mov_b32 s46, %0\n\ts_mov_b32 s47, %0\n\t"
+        "s_mov_b32 s48, %0\n\ts_mov_b32 s49, %0\n\ts_mov_b32 s50, %0\n\ts_mov_b32 s51, %0\n\ts_mov_b32 s52, %0\n\ts_mov_b32 s53, %0\n\t"
+        "s_mov_b32 s54, %0\n\ts_mov_b32 s55, %0\n\ts_mov_b32 s56, %0\n\ts_mov_b32 s57, %0\n\ts_mov_b32 s58, %0\n\ts_mov_b32 s59, %0\n\t"
+        "s_mov_b32 s60, %0\n\ts_mov_b32 s61, %0\n\ts_mov_b32 s62, %0\n\ts_mov_b32 s63, %0\n\ts_mov_b32 s64, %0\n\ts_mov_b32 s65, %0\n\t"
+        "s_mov_b32 s66, %0\n\ts_mov_b32 s67, %0\n\ts_mov_b32 s68, %0\n\ts_mov_b32 s69, %0\n\ts_mov_b32 s70, %0\n\ts_mov_b32 s71, %0\n\t"
+        "s_mov_b32 s72, %0\n\ts_mov_b32 s73, %0\n\ts_mov_b32 s74, %0\n\ts_mov_b32 s75, %0\n\ts_mov_b32 s76, %0\n\ts_mov_b32 s77, %0\n\t"
+        "s_mov_b32 s78, %0\n\ts_mov_b32 s79, %0\n\ts_mov_b32 s80, %0\n\ts_mov_b32 s81, %0\n\ts_mov_b32 s82, %0\n\ts_mov_b32 s83, %0\n\t"
+        "s_mov_b32 s84, %0\n\ts_mov_b32 s85, %0\n\ts_mov_b32 s86, %0\n\ts_mov_b32 s87, %0\n\ts_mov_b32 s88, %0\n\ts_mov_b32 s89, %0\n\t"
+        "s_mov_b32 s90, %0\n\ts_mov_b32 s91, %0\n\ts_mov_b32 s92, %0\n\ts_mov_b32 s93, %0\n\ts_mov_b32 s94, %0\n\ts_mov_b32 s95, %0\n\t"
+        "s_mov_b32 s96, %0\n\ts_mov_b32 s97, %0\n\ts_mov_b32 s98, %0\n\ts_mov_b32 s99, %0\n\t"
+        "s_nop 0"
+        :: "s"(pat)
+        :
+          "v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24",
+          "v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48",
+          "v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72",
+          "v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96",
+          "v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120",
+          "v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144",
+          "v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159",
+          "s4","s5","s6","s7","s8","s9","s10","s11","s12","s13","s14","s15","s16","s17","s18","s19","s20","s21","s22","s23","s24","s25","s26","s27",
+          "s28","s29","s30","s31","s34","s35","s36","s37","s38","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53",
+          "s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s68","s69","s70","s71","s72","s73","s74","s75","s76","s77",
+          "s78","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93","s94","s95","s96","s97","s98","s99");
+}
+#endif
+
 // VEC: float4 registers a thread holds while staging its channel (8: operand rows of 4..32 positions,
 // nb * Lin <= 32; 16: 64 positions).  PREF: request the next K block's operand before the current MFMAs.
 // LEAN (wide form only): the same arithmetic in half the registers and 40 KB of LDS, so that FOUR workgroups share a CU
@@ -399,6 +510,11 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #endif
     float *red = reinterpret_cast<float *>(lds_raw + A.off_red);        // [3][1024] + flag (lean form: the flag alone)
 
+#if defined(SURFD_C2_DBG_POISON) && SURFD_C2_DBG_POISON
+    c2_poison_registers<!LEAN>();
+    for (int e = threadIdx.x; e < A.C2_LDS_BYTES / 4; e += 256) reinterpret_cast<unsigned *>(lds_raw)[e] = SURFD_C2_DBG_POISON == 2 ? 0x7fc00000u : 0u;
+    lds_bar();
+#endif
     c2_kernarg_prefetch<(int)sizeof(Conv2Args)>();
     const int tid = threadIdx.x, lane = tid & 63;
     // provably wave-uniform: everything derived from it (k-part, column tile, iteration ranges, weight bases) stays in SGPRs
@@ -626,6 +742,9 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     if constexpr (!EPI_LATE) request_epilogue();
     bool saturated = false;
     C2_STAMP(1);
+#ifdef SURFD_C2_PROBE
+    unsigned long long probe_w = 0ull;
+#endif
 
     while (true) {
         // =========================== stage K block `ch` into the slab ===============================
@@ -640,6 +759,17 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             const int rowbase = rhalf * ((VEC * 4) >> A.seg[s].log2Lin);
             const int pad = A.seg[s].taps == 3 ? 1 : 0;
             const int ups = A.seg[s].ups, act = A.seg[s].act;
+#ifdef SURFD_C2_PROBE
+            {
+                unsigned long long h = 0ull;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) h += (unsigned long long)__float_as_uint(v[j][k]) * (unsigned long long)(2 * ((ch * 256 + tid) * 64 + j * 4 + k) + 1);
+                h += (unsigned long long)__float_as_uint(ga) * 7ull + (unsigned long long)__float_as_uint(be) * 11ull;
+                C2_PROBE_ADD(0, h);
+            }
+#endif
 #if defined(SURFD_C2_DBG_WAITALL)      // developer aid: every outstanding load has landed before the operand is touched
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -787,6 +917,17 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     }
                 }
 #endif
+#ifdef SURFD_C2_PROBE
+                {
+                    unsigned long long h = 0ull;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const bool live = rowbase + (j >> lv) < nb;          // rows past the batch chunk hold values nobody uses
+                        h += live ? ((unsigned long long)__float_as_uint(gmr[j]) + 3ull * __float_as_uint(gscr[j])) * (unsigned long long)(2 * ((ch * 256 + tid) * 16 + j) + 1) : 0ull;
+                    }
+                    C2_PROBE_ADD(1, cok ? h : 0ull);
+                }
+#endif
 #if !SURFD_C2_GNW
                 if constexpr (ALIAS) lds_bar();
 #endif
@@ -815,6 +956,18 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             //      ds_write_b16_d16_hi; the low plane sits at a compile-time offset (an LDS immediate, no address math).
             const int rstep = ups ? 2 : 1;
             const int Lcov = ups ? 2 * Lin : Lin;
+#ifdef SURFD_C2_PROBE
+            {
+                unsigned long long h = 0ull;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const bool live = rowbase + (j >> lv) < nb;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) h += live ? (unsigned long long)__float_as_uint(v[j][k]) * (unsigned long long)(2 * ((ch * 256 + tid) * 64 + j * 4 + k) + 1) : 0ull;
+                }
+                C2_PROBE_ADD(2, cok ? h : 0ull);
+            }
+#endif
             if (cok) {
                 float amax = 0.f;
 #pragma unroll
@@ -850,6 +1003,19 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                 }
             lds_bar();
             C2_STAMP_FIRST(4);
+#ifdef SURFD_C2_PROBE
+            {   // the slab as the matrix instructions will read it: every (batch row, position, channel < blkp) of both planes
+                unsigned long long h = 0ull;
+                const int n = nb * A.Lsl * blkp;
+                for (int e = tid; e < n; e += 256) {
+                    const int cch = e % blkp, rp = e / blkp;
+                    const unsigned short hi = __builtin_bit_cast(unsigned short, slab[rp * cs + cch]), lo = __builtin_bit_cast(unsigned short, slab[rp * cs + cch + PLANE]);
+                    h += ((unsigned long long)hi + 65537ull * lo) * (unsigned long long)(2 * (ch * 65536 + e) + 1);
+                }
+                C2_PROBE_ADD(3, h);
+                lds_bar();
+            }
+#endif
         }
         // =========================== MFMAs of this K block ============================================
         const int chn = ch + A.KS;
@@ -864,11 +1030,37 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #pragma unroll
             for (int t = 0; t < NCT; ++t) lbase[t] = (colb[t] * A.Lsl + coll[t] * A.seg[s].stride) * cs + 8 * (lane >> 5);
             const int nk = cur.nk;
+#if SURFD_C2_BPIPE
+            // B operand (the slab's two fp16 planes) of the NEXT k16 step, requested before the matrix instructions of the current
+            // one (round 6, profiles/r06_conv2_instability.md): (i) the LDS round trip of a step hides behind the previous step's
+            // three MFMAs instead of standing in front of them twice per step; (ii) a load never writes the source registers of a
+            // matrix instruction issued just before it — the registers it targets held the operand of the step BEFORE the
+            // current one.  Steps of a wave run it_beg, it_beg + 1, ... (the skipped ones are all at the tail), so "next" is
+            // it + 1; the last step re-reads itself.
+            f16x8 nbh, nbl;
+            auto bload = [&](int it, f16x8 &h, f16x8 &l) {
+                const int tap = (it >= nk) + (it >= 2 * nk);
+                const _Float16 *bp = slab + lbase[0] + tap * cs + (it - tap * nk) * 16;
+                h = *reinterpret_cast<const f16x8 *>(bp);
+                l = *reinterpret_cast<const f16x8 *>(bp + PLANE);
+            };
+            if constexpr (!NT2) bload(min(cur.it_beg, max(cur.it_end - 1, 0)), nbh, nbl);
+#endif
             auto compute = [&](const f16x8 (&a)[C2_U][2], int g) {
 #pragma unroll
                 for (int u = 0; u < C2_U; ++u) {
                     const int it = cur.it_beg + g * C2_U + u;
                     if (it < cur.it_end) {          // wave-uniform (scalar branch); only LDS reads and MFMAs inside: vmcnt bookkeeping unaffected
+#ifdef SURFD_C2_PROBE
+                        {
+                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 wa = __builtin_bit_cast(u32x4, a[u][0]), wb = __builtin_bit_cast(u32x4, a[u][1]);
+                            unsigned long long hw = 0ull;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) hw += ((unsigned long long)wa[q] + 5ull * wb[q]) * (unsigned long long)(2 * (((ch * 64 + it) * 256 + tid) * 4 + q) + 1);
+                            probe_w += hw;
+                        }
+#endif
                         const int tap = (it >= nk) + (it >= 2 * nk);
                         const int koff = tap * cs + (it - tap * nk) * 16;
                         if constexpr (NT2) {
@@ -883,9 +1075,15 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                             acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh0, acc_hh[0], 0, 0, 0);
                             acc_hh[NCT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh1, acc_hh[NCT - 1], 0, 0, 0);
                         } else {
+#if SURFD_C2_BPIPE
+                        (void)koff;
+                        const f16x8 bh = nbh, bl = nbl;
+                        bload(min(it + 1, cur.it_end - 1), nbh, nbl);
+#else
                         const _Float16 *bp = slab + lbase[0] + koff;
                         const f16x8 bh = *reinterpret_cast<const f16x8 *>(bp);
                         const f16x8 bl = *reinterpret_cast<const f16x8 *>(bp + PLANE);
+#endif
 #if defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 1      // developer aid: no matrix work (operands still fetched)
                         acc_sm[0][0] += (float)a[u][1][0] + (float)bh[0]; acc_hh[0][0] += (float)a[u][0][0] + (float)bl[0];
 #else
@@ -898,6 +1096,12 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                         acc_hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bh, acc_hh[0], 0, 0, 0);
                         acc_sm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm[0], 0, 0, 0);
                         }
+#endif
+#if SURFD_C2_BPIPE
+                        // this step's operand registers stay allocated until here: the loads of the next step's operand (issued
+                        // above, ordered before this statement by its memory clobber) cannot be given the registers the matrix
+                        // instructions of this step are still reading
+                        asm volatile("" :: "v"(bh), "v"(bl) : "memory");
 #endif
                         }
                     }
@@ -966,6 +1170,17 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     }
     const bool owner = WT ? tile_ok : kpart == 0;      // this wave holds a finished tile of the workgroup's K slice
     C2_STAMP(7);
+#ifdef SURFD_C2_PROBE
+    {
+        C2_PROBE_ADD(4, tile_ok ? probe_w : 0ull);
+        unsigned long long h = 0ull;
+#pragma unroll
+        for (int t = 0; t < NCT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h += (unsigned long long)__float_as_uint(acc[t][r]) * (unsigned long long)(2 * ((tid * NCT + t) * 16 + r) + 1);
+        C2_PROBE_ADD(5, owner ? h : 0ull);
+    }
+#endif
     // ---- cross-workgroup K reduction (hand-off recipe R1, cdna_hip_programming.md §6 G16): write-through
     //      partial tiles -> vmcnt(0) -> barrier -> relaxed ticket; the last arriver acquires and sums in slice order
     if (A.KS > 1) {
@@ -1029,6 +1244,11 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             if (mok && co < A.Cout) {
                 const float val = acc[t][r] * inv_sc + ((pre_b[r >> 2][r & 3] + (A.has_emb ? pre_e[t][r >> 2][r & 3] : 0.f)) + (A.has_res ? pre_r[t][r] : 0.f));
                 A.out[b * A.out_bstride + (long)co * A.Lout + l] = val;
+#ifdef SURFD_C2_PROBE
+                C2_PROBE_ADD(6, (unsigned long long)__float_as_uint(val) * (unsigned long long)(2 * ((tid * NCT + t) * 16 + r) + 1));
+                C2_PROBE_ADD(7, ((unsigned long long)__float_as_uint(pre_b[r >> 2][r & 3]) + 3ull * __float_as_uint(A.has_emb ? pre_e[t][r >> 2][r & 3] : 0.f) + 5ull * __float_as_uint(A.has_res ? pre_r[t][r] : 0.f))
+                                    * (unsigned long long)(2 * ((tid * NCT + t) * 16 + r) + 1));
+#endif
                 if constexpr (LF) {
                     // x0 prediction -> x_{t-1}, in place (this element of x is read and written by this thread only)
                     const long n = (long)A.B * A.Cout * A.Lout, e = ((long)b * A.Cout + co) * A.Lout + l;
@@ -1383,7 +1603,9 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     if (lds > 160 * 1024) return 1;
     A.whf = u->whf + c.whf_off; A.KS16 = c.KS16;
     if (nt2) { A.whf = u->whf2 + c.whf2_off; A.KS16 = c.KS16_2; }
+#if !(defined(SURFD_C2_PROBE) || defined(SURFD_C2_DBG_POISON))
     A.sc = u->wsc + (size_t)c.sc_idx * 4;
+#endif
     A.inv_sc = u->wsc_host[(size_t)c.sc_idx * 4 + 1];
     A.bias = u->vecs + c.bias_off;
     A.emb = A.bias; A.emb_bstride = 0; A.res = A.bias; A.res_bstride = 0; A.res_cstride = 1; A.res_lstride = 0;
@@ -1502,6 +1724,13 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
             A.pf_magic_ks = (unsigned)((0x100000000ULL + R.KS - 1) / R.KS);
         }
     }
+#if defined(SURFD_C2_PROBE) || defined(SURFD_C2_DBG_POISON)
+    {
+        static unsigned long long *const probe_base = [] { const char *e = getenv("SURFD_CONV2_PROBE_PTR"); return e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr; }();
+        A.probe = (probe_base && grid.x <= 4096 && c.id < 128) ? probe_base + (size_t)c.id * 4096 * 8 : nullptr;
+        A.C2_LDS_BYTES = (int)lds;
+    }
+#endif
     auto launch = [&]() {
         if (A.lf) {         // the head of a graph-replayed loop: same decompositions, posterior update in the epilogue
             if (wt && VEC == 16) hipLaunchKernelGGL((conv2_kernel<16, false, true, false, true>), grid, dim3(256), lds, st, A);

@@ -1301,7 +1301,9 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
     // Sustained shader clock of this launch: the kernel is power-bound, its rate follows the clock the chip can
     // hold under it.  Workgroup 0 (persistent: it runs from the first tile to the last) notes the shader-cycle counter and the
     // 100 MHz real-time counter now and adds the differences to the handle's record when it leaves; the start values wait in
-    // memory, not in registers (the kernel sits at its 256-register / SGPR limit).
+    // the workgroup's OWN LDS (behind LOG: the forward kernel uses nothing there), not in registers (the kernel sits at its
+    // 256-register / SGPR limit) and not in the handle's record (round 5: two launches on one handle that overlap — batch-grid
+    // pipelines, several streams — overwrote each other's start values there and added wrapped differences).
     // Experiment (-DSURFD_DEC_XCD_STAGGER=k, default off): the workgroups of XCD x (block b runs on XCD b % 8)
     // start x * k sleeps of ~4.8 us late, so that the eight XCDs walk the 11 layers out of phase (k = 6: an eighth of a tile's
     // ~215 us per XCD) instead of fetching the same 1 MB of a layer's planes from the fabric at the same moment.
@@ -1316,9 +1318,10 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
 #endif
 #if SURFD_DEC_CLOCK
     unsigned long long *const clk = reinterpret_cast<unsigned long long *>(P.sat + 2);
+    unsigned long long *const clk0 = reinterpret_cast<unsigned long long *>(LOG + TP);       // 8-byte aligned: (TP * XS + TP * 4 + TP) floats
     if (blockIdx.x == 0 && tid == 0) {
-        clk[0] = (unsigned long long)__builtin_readcyclecounter();
-        clk[1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        clk0[0] = (unsigned long long)__builtin_readcyclecounter();
+        clk0[1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     }
 #endif
     int sat_flag = 0;
@@ -1491,8 +1494,8 @@ __global__ __launch_bounds__(512, 1) void decoder_fwd8_kernel(DecParams P, PtBat
 #if SURFD_DEC_CLOCK
     if (blockIdx.x == 0 && tid == 0) {
         const unsigned long long c1 = (unsigned long long)__builtin_readcyclecounter(), r1 = (unsigned long long)__builtin_amdgcn_s_memrealtime();
-        atomicAdd(clk + 2, c1 - clk[0]);
-        atomicAdd(clk + 3, r1 - clk[1]);
+        atomicAdd(clk + 2, c1 - clk0[0]);        // same thread wrote them: program order, no barrier
+        atomicAdd(clk + 3, r1 - clk0[1]);
     }
 #endif
 }
@@ -1857,7 +1860,10 @@ int surfd_decoder_sustained_clock(surfd_decoder *d, int reset, double *ghz, surf
     HIP_TRY(hipMemcpyAsync(v, clk, sizeof(v), hipMemcpyDeviceToHost, st));
     if (reset) HIP_TRY(hipMemsetAsync(clk + 2, 0, 2 * sizeof(unsigned long long), st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (v[3] > 0) *ghz = (double)v[2] / ((double)v[3] * 10.0);        // cycles per 10 ns tick = GHz x 10
+    if (v[3] > 0) {
+        const double g = (double)v[2] / ((double)v[3] * 10.0);        // cycles per 10 ns tick = GHz x 10
+        if (g > 0.0 && g <= 3.0) *ghz = g;                            // anything else is not a clock (a wrapped counter): reported as "not measured"
+    }
     return SURFD_OK;
 }
 

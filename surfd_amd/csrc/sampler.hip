@@ -158,8 +158,14 @@ int surfd_sample_loop_begin(surfd_unet *u, const surfd_sampler_cfg *cfg, const f
     if (rc) return rc;
     LoopState *ls = unet_loop_state(u);
     if (!ls->step_ctr) {
-        HIP_TRY(hipMalloc((void **)&ls->step_ctr, 2 * sizeof(int)));
+        // the polling stream of surfd_unet_loop_progress is made HERE, before the counter exists: the progress thread only ever
+        // READS the two fields (it returns -1 while step_ctr is null), it never allocates beside this call
+        if (!ls->poll_stream) HIP_TRY(hipStreamCreateWithFlags(&ls->poll_stream, hipStreamNonBlocking));
+        int *ctr = nullptr;
+        HIP_TRY(hipMalloc((void **)&ctr, 2 * sizeof(int)));
         HIP_TRY(hipMalloc(&ls->params, sizeof(LoopParams) + sizeof(LoopFuse)));
+        HIP_TRY(hipMemsetAsync(ctr, 0, 2 * sizeof(int), st));
+        __atomic_store_n(&ls->step_ctr, ctr, __ATOMIC_RELEASE);
     }
     if ((size_t)n > ls->cap) {
         if (ls->x) HIP_TRY(hipFree(ls->x));
@@ -272,11 +278,19 @@ int surfd_unet_loop_progress(surfd_unet *u, int *iteration) {
     if (!u || !iteration) SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_loop_progress: null argument");
     LoopState *ls = unet_loop_state(u);
     *iteration = -1;
-    if (!ls->step_ctr) return SURFD_OK;
-    if (!ls->poll_stream) HIP_TRY(hipStreamCreateWithFlags(&ls->poll_stream, hipStreamNonBlocking));
+    int *ctr = __atomic_load_n(&ls->step_ctr, __ATOMIC_ACQUIRE);
+    if (!ctr || !ls->poll_stream) return SURFD_OK;       // both are made by surfd_sample_loop_begin; this call only reads them
+    // HIP's current device is per host thread and defaults to 0: a fresh progress thread polling a model on device N would copy
+    // from device-N memory over a device-0 context.  The handle's device is current for the copy and put back afterwards.
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
+    const int dev = unet_device(u);
+    if (dev >= 0 && dev != prev) HIP_TRY(hipSetDevice(dev));
     int v = 0;
-    HIP_TRY(hipMemcpyAsync(&v, ls->step_ctr, sizeof(int), hipMemcpyDeviceToHost, ls->poll_stream));
-    HIP_TRY(hipStreamSynchronize(ls->poll_stream));
+    hipError_t e = hipMemcpyAsync(&v, ctr, sizeof(int), hipMemcpyDeviceToHost, ls->poll_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ls->poll_stream);
+    if (dev >= 0 && dev != prev) (void)hipSetDevice(prev);
+    if (e != hipSuccess) SURFD_FAIL(SURFD_ERR_HIP, "surfd_unet_loop_progress: %s", hipGetErrorString(e));
     *iteration = v;
     return SURFD_OK;
 }

@@ -1487,6 +1487,7 @@ int unet_prepare_embeddings(surfd_unet *u, const int64_t *t_rows_host, int rows,
 }
 
 LoopState *unet_loop_state(surfd_unet *u) { return &u->loop; }
+int unet_device(surfd_unet *u) { return u->device; }
 long unet_workspace_generation(surfd_unet *u) { return u->ws_gen; }
 
 // one op of the denoiser body: x / out are the external input / output of the whole network

@@ -76,6 +76,7 @@ struct LoopState {
     long key[6] = {0, 0, 0, 0, 0, 0};
 };
 LoopState *unet_loop_state(surfd_unet *u);
+int unet_device(surfd_unet *u);          // the device the handle was allocated on (-1 before the first device call)
 // changes whenever a device buffer that a captured loop graph refers to is reallocated (or the kernel choice changes)
 long unet_workspace_generation(surfd_unet *u);
 }  // namespace surfd

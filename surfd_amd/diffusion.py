@@ -325,6 +325,9 @@ class SpacedDiffusion:
                 "stream": torch.cuda.Stream, "model_kwargs": {...} (optional)}, ...]   ->  [latents [B, 1, L] per job]
         Every job's stream waits for the current stream first (wait_current=False: the caller has ordered the streams itself);
         the caller waits on the job streams (or records events) after."""
+        chunk = int(chunk)
+        if chunk < 1:
+            raise ValueError(f"fused_loops_interleaved: chunk must be >= 1 iteration per turn, got {chunk}")
         opened = []
         cur = th.cuda.current_stream()
         T = self.num_timesteps
@@ -338,34 +341,51 @@ class SpacedDiffusion:
             if any(mdm is o for o in targets):
                 raise ValueError("fused_loops_interleaved: two jobs share one execution context (use MDM.replica())")
             targets.append(mdm)
-        for j, mdm in zip(jobs, targets):
-            dev = next(mdm.parameters()).device
-            st = j["stream"]
-            if wait_current:
-                st.wait_stream(cur)
-            with th.cuda.stream(st):
-                a = self._fused_inputs(mdm, tuple(j["shape"]), sampler, j.get("noise"), j.get("noise_stream"), clip_denoised,
-                                       j.get("model_kwargs"), eta, dev, False)
-                Lh, h = mdm._native()
-                N.check(Lh.surfd_sample_loop_begin(h, C.byref(a["cfg"]), N.ptr(a["noise"]), N.ptr(a["ctx"]), N.ptr(a["cls"]), None,
-                                                   a["B"], a["L"], N.stream()))
-            opened.append((mdm, a, st, Lh, h))
-        left = [T] * len(opened)
-        rem = C.c_int(0)
-        while any(left):
-            for q, (mdm, a, st, Lh, h) in enumerate(opened):
-                if left[q]:
-                    with th.cuda.stream(st):
-                        N.check(Lh.surfd_sample_loop_run(h, int(chunk), C.byref(rem), N.stream()))
-                    left[q] = int(rem.value)
         outs = []
-        for mdm, a, st, Lh, h in opened:
-            with th.cuda.stream(st):
-                N.check(Lh.surfd_sample_loop_end(h, N.ptr(a["out"]), N.stream()))
+        ok = False
+        try:
+            for j, mdm in zip(jobs, targets):
+                dev = next(mdm.parameters()).device
+                st = j["stream"]
+                if wait_current:
+                    st.wait_stream(cur)
+                with th.cuda.stream(st):
+                    a = self._fused_inputs(mdm, tuple(j["shape"]), sampler, j.get("noise"), j.get("noise_stream"), clip_denoised,
+                                           j.get("model_kwargs"), eta, dev, False)
+                    Lh, h = mdm._native()
+                    opened.append((mdm, a, st, Lh, h))   # before begin: a begin that fails half-way has already queued work reading a[...]
+                    N.check(Lh.surfd_sample_loop_begin(h, C.byref(a["cfg"]), N.ptr(a["noise"]), N.ptr(a["ctx"]), N.ptr(a["cls"]), None,
+                                                       a["B"], a["L"], N.stream()))
+            left = [T] * len(opened)
+            rem = C.c_int(0)
+            while any(left):
+                for q, (mdm, a, st, Lh, h) in enumerate(opened):
+                    if left[q]:
+                        with th.cuda.stream(st):
+                            N.check(Lh.surfd_sample_loop_run(h, chunk, C.byref(rem), N.stream()))
+                        if int(rem.value) >= left[q]:
+                            raise RuntimeError("fused_loops_interleaved: surfd_sample_loop_run made no progress")
+                        left[q] = int(rem.value)
+            for mdm, a, st, Lh, h in opened:
+                with th.cuda.stream(st):
+                    N.check(Lh.surfd_sample_loop_end(h, N.ptr(a["out"]), N.stream()))
+                outs.append(a["out"])
+            ok = True
+        finally:
+            # the replays queued so far read noise / ctx / cls on the job streams whether or not every call succeeded: the caching
+            # allocator must not hand that memory out again before those streams have passed this point
+            for mdm, a, st, Lh, h in opened:
                 for k in ("noise", "ctx", "cls"):
                     if a[k] is not None:
                         a[k].record_stream(st)
-            outs.append(a["out"])
+            if not ok:
+                # a loop that was opened and not closed: let what is in flight drain, then abandon it (the next begin on the
+                # handle drops the open loop's state, csrc/sampler.hip)
+                for mdm, a, st, Lh, h in opened:
+                    try:
+                        st.synchronize()
+                    except Exception:
+                        pass
         self.time_con.extend([(time.time() - t0) / T] * T)
         return outs
 

@@ -480,6 +480,35 @@ def test_grid_512_properties(D):
     same = direct == stored
     assert bool((stored[~same] >= float(torch.tensor(1.5 * 1.7 * (2.0 / 256), dtype=torch.float32))).all())
     assert dec.saturation_count() == 0
+    # ---- the ORACLE at this size: voxels the fill evaluated AT the 512 level, and voxels that carry a gradient,
+    #      against the CPU restatement of the reference's decoder (meshudf.py:123-206 decides which voxels those are).
+    #      A voxel with an odd index whose 256-level parent corner (all indices rounded down to even) holds a value below that
+    #      level's refine threshold sits in a refined block: a parent that was itself only a copy would hold a coarser level's
+    #      "not close" value (>= 0.0398), so the parent was evaluated, was close, and the voxel was evaluated at the 512 level.
+    thr256 = float(torch.tensor(ogrid.refine_threshold(256), dtype=torch.float32))
+    g2 = torch.Generator().manual_seed(23)
+    cand = torch.randint(0, 512 ** 3, (4_000_000,), generator=g2).cuda()
+    ci, cj, ck = cand // (512 * 512), (cand // 512) % 512, cand % 512
+    odd = ((ci | cj | ck) & 1) == 1
+    parent = ((ci & ~1) * 512 + (cj & ~1)) * 512 + (ck & ~1)
+    flat = udf.reshape(-1)
+    at512 = cand[odd & (flat[parent] < thr256)]
+    assert len(at512) >= 4096, len(at512)
+    at512 = at512[:4096].cpu()
+    gflat = grads.reshape(-1, 3)
+    gcand = torch.nonzero(has.reshape(-1)).flatten()
+    gsel = gcand[torch.randperm(len(gcand), generator=g2)[:4096].cuda()].cpu()
+    f = odec.make_udf_func(sd, lat.cpu())
+    for name, sel in (("evaluated at the 512 level", at512), ("gradient voxels", gsel)):
+        i, j, k = sel // (512 * 512), (sel // 512) % 512, sel % 512
+        pts = torch.stack([ax[i], ax[j], ax[k]], 1)
+        ref = odec.sample_udf(f, pts, 2 ** 16)
+        got = flat[sel.cuda()].cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-6, err_msg=f"D={D}: {name}")
+    pts = torch.stack([ax[gsel // (512 * 512)], ax[(gsel // 512) % 512], ax[gsel % 512]], 1)
+    refg = odec.sample_grads(f, pts, 2 ** 12).numpy()
+    nz = np.linalg.norm(refg, axis=-1) > 0
+    _check_directions(_cos(gflat[gsel.cuda()].cpu().numpy(), refg)[nz], label=f" (512^3 grid, D={D})")
     del udf, grads, udf2, grads2
     torch.cuda.empty_cache()
 
