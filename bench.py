@@ -124,6 +124,8 @@ def parse():
     ap.add_argument("--no-trace-e2", action="store_true", help="skip the timed W-trace / E2 pass (trained-model-like field through marching cubes)")
     ap.add_argument("--trace-steps", type=int, default=0, help="steps timed by the W-trace / E2 pass (0 = --steps)")
     a = ap.parse_args()
+    if a.loop_chunk < 1:
+        ap.error("--loop-chunk must be >= 1 graph replay per loop and turn")
     cfg = CONFIGS[a.config]
     if a.resolution is None:
         a.resolution = cfg["resolution"]
@@ -395,12 +397,22 @@ def time_trace(dec, lat, lists, reps=2):
             "fwd_bwd_algorithmic_tflops": n_g * 2 * FWD_FLOP / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0}
 
 
+def build_config():
+    """The compile-time configuration of the loaded libsurfd_hip.so (surfd_build_config: every experiment macro of the kernel
+    sources with the value it was built with, and how many of them select a variant recorded as unsafe)."""
+    from surfd_amd import _native as Nn
+    try:
+        return Nn.lib().surfd_build_config().decode()
+    except Exception as e:      # an older library without the export
+        return f"unknown ({type(e).__name__})"
+
+
 def committed_traffic():
     """(profile, note): HBM traffic of the dominant kernels from the committed PMC passes of this command (profiles/,
     collected in their own rocprofv3 --pmc runs as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per the gfx950 note).
     A profile names the kernel sources it was collected with (sha256); if they have changed since, nothing is quoted."""
     import hashlib
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -727,9 +739,21 @@ def main():
         k = max(1, min(a.strict_steps, n_steps_max))
         sm = sj.measure(k, 1)
         sj.close()
+        loop_s = sm["prof"]["loop"][1] / max(sm["prof"]["loop"][0], 1) * 1e-3
+        # the latency form against ITS roof (the weakest number of the repository belongs in the line): 8 latents
+        # per evaluation are far below the ridge, the weight stream (553 MB at the HBM peak) is what bounds an evaluation
+        s_flops = B * UNET_FLOP_PER_SAMPLE.get(a.latent, 2.057e9 * a.latent / 32)
+        s_unet_peak = F16_MFMA_PEAK_TF / 3.0 if a.unet_precision == "f16x2" else FP32_MFMA_PEAK_TF
+        s_hbm_us, s_mfma_us = UNET_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e9) * 1e6, s_flops / (s_unet_peak * 1e12) * 1e6
+        s_eval_us = loop_s / T * 1e6
         strict = {"value": B * k / sm["elapsed"], "unit": "shapes/s", "latency_s_per_request": sm["elapsed"] / k, "requests": k, "warmup": 1,
                   "shapes_per_request": B, "requests_in_flight": 1,
-                  "reverse_loop_s_per_request": sm["prof"]["loop"][1] / max(sm["prof"]["loop"][0], 1) * 1e-3,
+                  "reverse_loop_s_per_request": loop_s,
+                  "roofline": {"kernel": "conv2_kernel (latency form: one 32-row tile per workgroup, K split follows the batch) x84 + attn_kernel x16 per evaluation",
+                               "bound": "hbm" if s_hbm_us >= s_mfma_us else "mfma", "us_per_evaluation": s_eval_us,
+                               "roof_us_hbm": s_hbm_us, "roof_us_mfma": s_mfma_us,
+                               "achieved": UNET_WEIGHT_BYTES / (s_eval_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s (weight stream: 553 MB per evaluation)",
+                               "frac": max(s_hbm_us, s_mfma_us) / s_eval_us, "latents_per_evaluation": B},
                   "what": "one batch-8 request in flight per GPU (BASELINE configs[2] = batch 64 over 8 GPUs, read strictly): 1000-step loop over 8 "
                           "latents (latency form of the conv kernel), then the request's 8 grids, sequentially on one stream"}
     trace_e2 = None
@@ -813,6 +837,8 @@ def main():
                      "achieved": (n_chains * flops_eval / (sched_ms_eval * 1e-3) / 1e12) if (sched_ms_eval and binding == "mfma") else streamed_gbs,
                      "peak": unet_peak if binding == "mfma" else HBM_PEAK_GBS, "unit": "TFLOP/s (algorithmic; x3 issued on the fp16 pipe)" if binding == "mfma" else "GB/s",
                      "traffic": (pmc or {}).get("unet_eval_hbm_bytes"),
+                     "traffic_over_algorithmic": ((pmc or {}).get("unet_eval_fetch_bytes") / UNET_WEIGHT_BYTES) if (pmc or {}).get("unet_eval_fetch_bytes") else None,
+                     "traffic_over_algorithmic_means": "fabric-side FETCH bytes per evaluation (committed PMC pass) / the 553 MB of weights an evaluation needs once",
                      "traffic_from": pmc_note,
                      "algorithmic_bytes_per_evaluation": UNET_WEIGHT_BYTES, "algorithmic_flop_per_evaluation": flops_eval,
                      "latents_per_loop": lat_per_loop, "loops_in_flight": n_chains, "loops": loops,
@@ -843,6 +869,7 @@ def main():
                    "loop_driver": (a.loop_driver + (f" (one host thread, {a.loop_chunk} graph replay(s) per loop and turn)" if a.loop_driver == "interleaved" else " (one host thread per loop)")) if a.schedule == "phased" else "n/a",
                    "rounds": meas["rounds"], "rounds_means": "time-sliced rounds inside the timed region (loops of a round, then its grids); 1 = the whole region is one round",
                    "startup_s": meas["startup_s"],
+                   "build_flags": build_config(),
                    "host_threads_per_rank": {"loop_chains": n_chains, "loop_driver_threads": 1 if (a.schedule == "phased" and a.loop_driver == "interleaved") else n_chains, "meshing": (mesh_stats or {}).get("threads", 0), "host_cores": os.cpu_count(), "ranks": world,
                                              "cpus_of_rank_0": _cpu_ranges(PINNED_CPUS) if PINNED_CPUS else "not pinned (one rank)"},
                    "parallelism": f"shape-parallel x{world}, no data-path collective (latents all_gathered after the timed region)"},

@@ -42,6 +42,11 @@ const char *surfd_last_error(void);
 int surfd_abi_version(void);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int surfd_device_count(void);
+/* Compile-time configuration of the library (no reference counterpart): "name=value" for every experiment macro of the kernel
+ * sources, then "unsafe_variants=N" = how many of them select a variant recorded as wrong, not bit-stable, or a developer aid
+ * (0 for the product build: such variants need -DSURFD_ALLOW_UNSAFE_VARIANTS to compile at all).  bench.py prints it as
+ * config.build_flags; tests/test_abi_cpu.py asserts the shipped library was built with the defaults.  Static storage. */
+const char *surfd_build_config(void);
 
 /* Measurement aid (no reference counterpart): when enabled, the library brackets its dominant
  * kernels with HIP events on the stream they are launched on.  kind 0 = decoder forward kernel,

@@ -42,6 +42,7 @@ _SIGS = {
     "surfd_last_error": (C.c_char_p, []),
     "surfd_abi_version": (C.c_int, []),
     "surfd_device_count": (C.c_int, []),
+    "surfd_build_config": (C.c_char_p, []),
     "surfd_profile_enable": (C.c_int, [C.c_int]),
     "surfd_profile_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),
     "surfd_unet_debug_read": (C.c_int, [_P, C.POINTER(C.c_longlong), C.c_int]),

@@ -75,4 +75,10 @@ bool prof_enabled();
 hipEvent_t prof_begin(int kind, hipStream_t st);                  // null when profiling is off
 void prof_end(int kind, hipEvent_t begin, hipStream_t st);
 
+// surfd_build_config: the experiment macros each kernel file was compiled with, and how many select a variant recorded as unsafe
+const char *conv2_build_config();      // conv_f16x2.hip
+int conv2_build_unsafe();
+const char *decoder_build_config();    // decoder.hip
+int decoder_build_unsafe();
+
 }  // namespace surfd

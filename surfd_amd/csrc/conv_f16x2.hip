@@ -106,6 +106,9 @@ struct Conv2Args {
 #ifndef SURFD_C2_BPIPE
 #define SURFD_C2_BPIPE 0
 #endif
+#ifndef SURFD_C2_LEAN_U
+#define SURFD_C2_LEAN_U 2
+#endif
 #ifndef SURFD_C2_LAT_D
 #define SURFD_C2_LAT_D 2
 #endif
@@ -217,6 +220,22 @@ __device__ __forceinline__ float c2_dpp(float x) {
 #else
 #define C2_OPAQUE(v) do { } while (0)
 #endif
+// SURFD_C2_GNPAD=n (round 6): n wait states between every add of the GroupNorm reductions and the cross-lane read (DPP,
+// ds_bpermute, v_permlane*_swap) of its result.  The statistics are the one quantity that goes wrong in the timing-dependent
+// failures of round 5 (profiles/r06_conv2_instability.md: 1/sigma of one or two groups short by about one lane's term, mean
+// right): a lane of the all-reduce worked with a neighbour's value from BEFORE that neighbour's last add.  The compiler's own
+// padding (s_nop 1 in front of a DPP read, nothing in front of ds_bpermute's data read) assumes the add's result reaches the
+// register file a fixed number of cycles after issue.
+#ifndef SURFD_C2_GNPAD
+#define SURFD_C2_GNPAD 0
+#endif
+__device__ __forceinline__ void c2_gnpad(float &x) {
+#if SURFD_C2_GNPAD > 0
+    asm volatile(".rept %1\n\ts_nop 0\n\t.endr" : "+v"(x) : "i"(SURFD_C2_GNPAD));
+#else
+    (void)x;
+#endif
+}
 // x[lane] + x[lane ^ W] for W = 16 / 32 on the vector ALU (gfx950: v_permlane16_swap / v_permlane32_swap exchange the odd
 // 16-lane rows / the upper half of the first operand with the even rows / the lower half of the second: with both operands x
 // the two results hold, in every lane, the two partners' values) — no LDS pipe, no lgkmcnt
@@ -228,29 +247,33 @@ __device__ __forceinline__ float c2_swap_sum(float x) {
 }
 template <int N>
 __device__ __forceinline__ void c2_slot_sum(float (&x)[N], int log2P) {
+#if SURFD_C2_GNPAD > 0
+#pragma unroll
+    for (int i = 0; i < N; ++i) c2_gnpad(x[i]);          // the leaves were written by the instruction before
+#endif
     if (log2P > 0) {         // quad_perm [1,0,3,2]: lane ^ 1
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0xB1>(x[i]); C2_OPAQUE(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0xB1>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 1) {         // quad_perm [2,3,0,1]: lane ^ 2
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x4E>(x[i]); C2_OPAQUE(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x4E>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 2) {         // row_half_mirror: the other quad of the 8
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x141>(x[i]); C2_OPAQUE(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x141>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 3) {         // row_mirror: the other half of the 16
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x140>(x[i]); C2_OPAQUE(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x140>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 4) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<16>(x[i]); C2_OPAQUE(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<16>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 5) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<32>(x[i]); C2_OPAQUE(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<32>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
     }
 }
 
@@ -492,9 +515,6 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
     // the register / LDS diet of the lean form, also applied to 64-position rows in the wide form (16 float4 of operand per
     // thread: without it the kernel spills 77 registers at two workgroups per CU)
     constexpr bool SLIM = LEAN || (WT && VEC == 16);
-#ifndef SURFD_C2_LEAN_U
-#define SURFD_C2_LEAN_U 2
-#endif
     // ONE accumulator per column tile (experiment SURFD_C2_LEAN_U=3: the 16 registers of the second one buy a third k16 step per
     // ring stage in the lean form)
     constexpr bool ONE_ACC = NT2 || (LEAN && SURFD_C2_LEAN_U == 3);
@@ -894,12 +914,12 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     float sm = 0.f;
                     if (qok)
                         for (int k = lt; k < gs; k += 8) sm += pm[k];
-                    sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 1);
+                    c2_gnpad(sm); sm += __shfl_xor(sm, 4); c2_gnpad(sm); sm += __shfl_xor(sm, 2); c2_gnpad(sm); sm += __shfl_xor(sm, 1); c2_gnpad(sm);
                     const float gm = sm * inv_gs;
                     float m2 = 0.f;
                     if (qok)
                         for (int k = lt; k < gs; k += 8) { const float d = pm[k] - gm; m2 += p2[k] + flin * (d * d); }
-                    m2 += __shfl_xor(m2, 4); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 1);
+                    c2_gnpad(m2); m2 += __shfl_xor(m2, 4); c2_gnpad(m2); m2 += __shfl_xor(m2, 2); c2_gnpad(m2); m2 += __shfl_xor(m2, 1); c2_gnpad(m2);
                     if (qok && lt == 0) { gstat[2 * q] = gm; gstat[2 * q + 1] = 1.f / sqrtf(m2 * inv_cnt + 1e-5f); }
                 }
                 lds_bar();
@@ -1097,10 +1117,12 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                         acc_sm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][0], bl, acc_sm[0], 0, 0, 0);
                         }
 #endif
-#if SURFD_C2_BPIPE
+#if SURFD_C2_BPIPE == 1
                         // this step's operand registers stay allocated until here: the loads of the next step's operand (issued
                         // above, ordered before this statement by its memory clobber) cannot be given the registers the matrix
-                        // instructions of this step are still reading
+                        // instructions of this step are still reading.  (SURFD_C2_BPIPE=2, the experiment's control: the same
+                        // request order WITHOUT this statement — the compiler then sinks the loads behind the last use of bl and
+                        // gives them bl's registers again.)
                         asm volatile("" :: "v"(bh), "v"(bl) : "memory");
 #endif
                         }
@@ -1770,6 +1792,73 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     LAUNCH_CHECK();
     return SURFD_OK;
 }
+
+// ---- the compiled configuration (surfd_build_config) and the fence around variants recorded as unsafe -----------------------------
+// Every experiment macro of this file with the value it was compiled with; `unsafe` counts the ones that select a variant known to
+// give wrong or not bit-stable results (profiles/r05_loop_experiments.md, profiles/r06_conv2_instability.md) or a developer aid that
+// changes the results.  Those do not compile unless SURFD_ALLOW_UNSAFE_VARIANTS is defined (tools/build_variants.py passes it for
+// the hunt's builds; the product build never does).
+#define C2_STR_(x) #x
+#define C2_STR(x) C2_STR_(x)
+#if defined(SURFD_C2_ABLATE)
+#define C2_CFG_ABLATE SURFD_C2_ABLATE
+#else
+#define C2_CFG_ABLATE 0
+#endif
+#if defined(SURFD_C2_DBG_POISON)
+#define C2_CFG_POISON SURFD_C2_DBG_POISON
+#else
+#define C2_CFG_POISON 0
+#endif
+#if defined(SURFD_C2_PROBE)
+#define C2_CFG_PROBE 1
+#else
+#define C2_CFG_PROBE 0
+#endif
+#if defined(SURFD_C2_STAMPS)
+#define C2_CFG_STAMPS 1
+#else
+#define C2_CFG_STAMPS 0
+#endif
+#if defined(SURFD_C2_PFN_NOLOAD) || defined(SURFD_C2_PFN_EARLYUSE) || defined(SURFD_C2_DBG_CLEARLDS) || defined(SURFD_C2_DBG_WAITALL) || defined(SURFD_C2_GNW_NOPK) || defined(SURFD_C2_GNW_ROWWISE) || defined(SURFD_C2_GNW_LIVEONLY)
+#define C2_CFG_DEVAIDS 1
+#else
+#define C2_CFG_DEVAIDS 0
+#endif
+#define C2_UNSAFE_COUNT ((SURFD_C2_GNW != 0) + (SURFD_C2_PFN_FORMS != 0) + (SURFD_C2_SC1_REDUCE != 0) + (SURFD_C2_LAT_D != 2) + (SURFD_C2_PFN_DMA != 0) + \
+                         (SURFD_C2_BPIPE == 2) + (C2_CFG_ABLATE != 0) + (C2_CFG_POISON != 0) + (C2_CFG_PROBE != 0) + (C2_CFG_DEVAIDS != 0))
+#if !defined(SURFD_ALLOW_UNSAFE_VARIANTS)
+#if SURFD_C2_GNW != 0
+#error "SURFD_C2_GNW=1 (in-wave GroupNorm) is recorded as NOT bit-stable run to run (profiles/r05_loop_experiments.md section 3); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#endif
+#if SURFD_C2_PFN_FORMS != 0
+#error "SURFD_C2_PFN_FORMS=1 (weight prefetch in every instantiation) gave wrong, non-repeatable results at L = 64 (profiles/r05_loop_experiments.md section 8); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#endif
+#if SURFD_C2_SC1_REDUCE != 0
+#error "SURFD_C2_SC1_REDUCE=1 reads split-K partials without the acquire: stale L2 copies (profiles/r05_loop_experiments.md section 3); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#endif
+#if SURFD_C2_LAT_D != 2
+#error "SURFD_C2_LAT_D != 2 is not a validated configuration of the latency form (profiles/r05_loop_experiments.md section 1); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#endif
+#if SURFD_C2_PFN_DMA != 0
+#error "SURFD_C2_PFN_DMA=1: M0's 16-bit LDS base wraps in the two-per-CU forms (the word lands in the slab); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#endif
+#if SURFD_C2_BPIPE == 2
+#error "SURFD_C2_BPIPE=2 is the control of an experiment (not bit-stable with SURFD_C2_GNW, profiles/r06_conv2_instability.md); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#endif
+#if C2_CFG_ABLATE != 0 || C2_CFG_POISON != 0 || C2_CFG_PROBE != 0 || C2_CFG_DEVAIDS != 0
+#error "developer aids of conv_f16x2.hip (SURFD_C2_ABLATE / _DBG_* / _PROBE / _PFN_NOLOAD ...) change results or timing; -DSURFD_ALLOW_UNSAFE_VARIANTS builds them anyway"
+#endif
+#endif
+const char *conv2_build_config() {
+    return "C2_GNW=" C2_STR(SURFD_C2_GNW) " C2_BPIPE=" C2_STR(SURFD_C2_BPIPE) " C2_GNPAD=" C2_STR(SURFD_C2_GNPAD) " C2_PFN=" C2_STR(SURFD_C2_PFN) " C2_PFN_FORMS=" C2_STR(SURFD_C2_PFN_FORMS)
+           " C2_PFN_N=" C2_STR(SURFD_C2_PFN_N) " C2_PFN_DMA=" C2_STR(SURFD_C2_PFN_DMA) " C2_SC1_REDUCE=" C2_STR(SURFD_C2_SC1_REDUCE) " C2_KAPF=" C2_STR(SURFD_C2_KAPF)
+           " C2_FAST_RCP=" C2_STR(SURFD_C2_FAST_RCP) " C2_EPI_LATE=" C2_STR(SURFD_C2_EPI_LATE) " C2_LAT_D=" C2_STR(SURFD_C2_LAT_D) " C2_DEEP_D=" C2_STR(SURFD_C2_DEEP_D)
+           " C2_LEAN_WAVES=" C2_STR(SURFD_C2_LEAN_WAVES) " C2_LEAN_U=" C2_STR(SURFD_C2_LEAN_U) " C2_PLANE_LEAN=" C2_STR(SURFD_C2_PLANE_LEAN)
+           " C2_ABLATE=" C2_STR(C2_CFG_ABLATE) " C2_DBG_POISON=" C2_STR(C2_CFG_POISON) " C2_PROBE=" C2_STR(C2_CFG_PROBE) " C2_STAMPS=" C2_STR(C2_CFG_STAMPS)
+           " C2_DEVAIDS=" C2_STR(C2_CFG_DEVAIDS);
+}
+int conv2_build_unsafe() { return C2_UNSAFE_COUNT; }
 
 int conv2_set_attributes() {
     const int max_lds = 160 * 1024;

@@ -1,6 +1,7 @@
 // Error reporting, version, device probe and the weight packer shared by all kernels.
 #include "common.h"
 #include <mutex>
+#include <string>
 
 namespace surfd {
 
@@ -89,6 +90,14 @@ int surfd_profile_read(int kind, int64_t *launches, double *total_ms) {
     return SURFD_OK;
 }
 const char *surfd_last_error(void) { return surfd::g_err; }
+// The compile-time configuration of this library: every experiment macro of the kernel sources with the value it was built with
+// ("name=value" pairs) and `unsafe_variants=N`, the number of them that select a variant recorded as wrong, not bit-stable or a
+// developer aid (0 for the product build; such variants only compile with -DSURFD_ALLOW_UNSAFE_VARIANTS).
+const char *surfd_build_config(void) {
+    static const std::string cfg = std::string("abi=1 ") + surfd::conv2_build_config() + " " + surfd::decoder_build_config() +
+                                   " unsafe_variants=" + std::to_string(surfd::conv2_build_unsafe() + surfd::decoder_build_unsafe());
+    return cfg.c_str();
+}
 int surfd_abi_version(void) { return 1; }
 int surfd_device_count(void) {
     int n = 0;

@@ -1582,6 +1582,32 @@ __global__ void cbn_table_kernel(CbnParams P, const float *lat, int S, int D, fl
 // =============================================================================================
 // host side
 // =============================================================================================
+// the compiled configuration of this file (surfd_build_config); SURFD_DEC_OVL is the one variant recorded as not to be shipped
+// (25 spilled registers, kept as the record of a measurement): fenced like conv_f16x2.hip's
+#define DEC_STR_(x) #x
+#define DEC_STR(x) DEC_STR_(x)
+#if defined(SURFD_DEC_W_NT) && SURFD_DEC_W_NT
+#define DEC_CFG_W_NT 1
+#else
+#define DEC_CFG_W_NT 0
+#endif
+#if defined(SURFD_DEC_STAMPS)
+#define DEC_CFG_STAMPS 1
+#else
+#define DEC_CFG_STAMPS 0
+#endif
+#if SURFD_DEC_OVL != 0 && !defined(SURFD_ALLOW_UNSAFE_VARIANTS)
+#error "SURFD_DEC_OVL=1 is an experiment kept as a record (profiles/r03_decoder_variants.md); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#endif
+namespace surfd {
+const char *decoder_build_config() {
+    return "DEC_OVL=" DEC_STR(SURFD_DEC_OVL) " DEC_MIX=" DEC_STR(SURFD_DEC_MIX) " DEC_GRAD_W=" DEC_STR(SURFD_DEC_GRAD_W) " DEC_GRAD_MIX=" DEC_STR(SURFD_DEC_GRAD_MIX)
+           " DEC_WS_AHEAD=" DEC_STR(SURFD_DEC_WS_AHEAD) " DEC_REQ_EARLY=" DEC_STR(SURFD_DEC_REQ_EARLY) " DEC_FWD_STAGED=" DEC_STR(SURFD_DEC_FWD_STAGED)
+           " DEC_XCD_STAGGER=" DEC_STR(SURFD_DEC_XCD_STAGGER) " DEC_CLOCK=" DEC_STR(SURFD_DEC_CLOCK) " DEC_W_NT=" DEC_STR(DEC_CFG_W_NT) " DEC_STAMPS=" DEC_STR(DEC_CFG_STAMPS);
+}
+int decoder_build_unsafe() { return SURFD_DEC_OVL != 0; }
+}  // namespace surfd
+
 using namespace surfd;
 
 struct DecTensor {

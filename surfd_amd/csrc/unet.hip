@@ -1569,6 +1569,7 @@ extern "C" int surfd_unet_debug_run_module(surfd_unet *u, const char *module, co
         if (in_mod) sel.push_back(&op);
         prev = in_mod;
     }
+    while (!sel.empty() && sel.back()->kind != 0) sel.pop_back();      // "input_blocks.1.1.qkv": the projection alone, without the attention core behind it
     if (sel.empty() || sel.front()->kind != 0 || sel.back()->kind != 0)
         SURFD_FAIL(SURFD_ERR_ARG, "surfd_unet_debug_run_module: no ops for module '%s'", module);
     const ConvPlan &first = sel.front()->conv, &last = sel.back()->conv;

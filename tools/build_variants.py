@@ -35,7 +35,7 @@ for spec in sys.argv[1:]:
         src = tmp
     obj = os.path.join(out_dir, f"{name}_{os.path.splitext(src_name)[0]}.o")
     try:
-        subprocess.check_call([B._hipcc()] + B.FLAGS + flags + ["-c", src, "-o", obj])
+        subprocess.check_call([B._hipcc()] + B.FLAGS + ["-DSURFD_ALLOW_UNSAFE_VARIANTS"] + flags + ["-c", src, "-o", obj])      # experiments: the fence of the unsafe variants is lifted here and only here
     finally:
         if tmp:
             os.remove(tmp)

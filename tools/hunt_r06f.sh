@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
+OUT=gpurun_out/hunt6; mkdir -p $OUT
+V=surfd_amd/lib/variants
+run() { local name=$1 lib=$2; shift 2; local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+    echo "== $name ($lib ${envs[*]}) :: $*" >> $OUT/summary.txt
+    env SURFD_LIB=$PWD/$V/libsurfd_hip_$lib.so "${envs[@]}" timeout 500 "$@" > $OUT/$name.txt 2>&1; echo "rc=$?" >> $OUT/$name.txt
+    grep -E '^\{|rc=' $OUT/$name.txt | cut -c1-200 >> $OUT/summary.txt; }
+run es_a0_qkv a0 -- python tools/error_structure.py input_blocks.1.1.qkv 224 672 64 64 30 80 32 64
+run es_g0_qkv g0 -- python tools/error_structure.py middle_block.1.qkv 896 2688 4 4 30 80 80 32
+run es_a0_qkv_40 a0 -- python tools/error_structure.py input_blocks.1.1.qkv 224 672 64 64 30 40 32 64
+cat $OUT/summary.txt
