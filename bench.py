@@ -397,6 +397,20 @@ def time_trace(dec, lat, lists, reps=2):
             "fwd_bwd_algorithmic_tflops": n_g * 2 * FWD_FLOP / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0}
 
 
+def latency_form_roofline(loop_s, T, B, latent, unet_precision):
+    """The reverse loop of ONE narrow request (the conv kernel's latency form, what sample/generate_* runs) against ITS roof
+    (the weakest number of the repository belongs in the driver line): B latents per evaluation are far below the
+    ridge, so the weight stream — 553 MB per evaluation at the HBM peak — bounds an evaluation; `frac` = roof time / measured time."""
+    flops = B * UNET_FLOP_PER_SAMPLE.get(latent, 2.057e9 * latent / 32)
+    unet_peak = F16_MFMA_PEAK_TF / 3.0 if unet_precision == "f16x2" else FP32_MFMA_PEAK_TF
+    hbm_us, mfma_us = UNET_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e9) * 1e6, flops / (unet_peak * 1e12) * 1e6
+    eval_us = loop_s / T * 1e6
+    return {"kernel": "conv2_kernel (latency form: one 32-row tile per workgroup, K split follows the batch) x84 + attn_kernel x16 per evaluation",
+            "bound": "hbm" if hbm_us >= mfma_us else "mfma", "us_per_evaluation": eval_us, "roof_us_hbm": hbm_us, "roof_us_mfma": mfma_us,
+            "achieved": UNET_WEIGHT_BYTES / (eval_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s (weight stream: 553 MB per evaluation)",
+            "frac": max(hbm_us, mfma_us) / eval_us, "latents_per_evaluation": B}
+
+
 def build_config():
     """The compile-time configuration of the loaded libsurfd_hip.so (surfd_build_config: every experiment macro of the kernel
     sources with the value it was built with, and how many of them select a variant recorded as unsafe)."""
@@ -740,20 +754,10 @@ def main():
         sm = sj.measure(k, 1)
         sj.close()
         loop_s = sm["prof"]["loop"][1] / max(sm["prof"]["loop"][0], 1) * 1e-3
-        # the latency form against ITS roof (the weakest number of the repository belongs in the line): 8 latents
-        # per evaluation are far below the ridge, the weight stream (553 MB at the HBM peak) is what bounds an evaluation
-        s_flops = B * UNET_FLOP_PER_SAMPLE.get(a.latent, 2.057e9 * a.latent / 32)
-        s_unet_peak = F16_MFMA_PEAK_TF / 3.0 if a.unet_precision == "f16x2" else FP32_MFMA_PEAK_TF
-        s_hbm_us, s_mfma_us = UNET_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e9) * 1e6, s_flops / (s_unet_peak * 1e12) * 1e6
-        s_eval_us = loop_s / T * 1e6
         strict = {"value": B * k / sm["elapsed"], "unit": "shapes/s", "latency_s_per_request": sm["elapsed"] / k, "requests": k, "warmup": 1,
                   "shapes_per_request": B, "requests_in_flight": 1,
                   "reverse_loop_s_per_request": loop_s,
-                  "roofline": {"kernel": "conv2_kernel (latency form: one 32-row tile per workgroup, K split follows the batch) x84 + attn_kernel x16 per evaluation",
-                               "bound": "hbm" if s_hbm_us >= s_mfma_us else "mfma", "us_per_evaluation": s_eval_us,
-                               "roof_us_hbm": s_hbm_us, "roof_us_mfma": s_mfma_us,
-                               "achieved": UNET_WEIGHT_BYTES / (s_eval_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s (weight stream: 553 MB per evaluation)",
-                               "frac": max(s_hbm_us, s_mfma_us) / s_eval_us, "latents_per_evaluation": B},
+                  "roofline": latency_form_roofline(loop_s, T, B, a.latent, a.unet_precision),
                   "what": "one batch-8 request in flight per GPU (BASELINE configs[2] = batch 64 over 8 GPUs, read strictly): 1000-step loop over 8 "
                           "latents (latency form of the conv kernel), then the request's 8 grids, sequentially on one stream"}
     trace_e2 = None
@@ -1007,9 +1011,13 @@ def grid_shard_main(a, world, rank):
         shard_caps = filler.shard_capacities(a.shard_capacity if fixed_caps else None, a.shard_grad_capacity if fixed_caps else None)
         assert cut == 0, (f"{cut} exchange buffer(s) of the timed region were shorter than their list (capacities {shard_caps}): the grids "
                           f"of this run are incomplete — raise --shard-capacity / --shard-grad-capacity")
-    # what one shape hands to the collective (every level's buffer + the gradient buffer; with one rank nothing is exchanged, the
-    # figure is what 2+ ranks would move per rank and shape); SURVEY.md §8e sized an all-gather at <= 5 MB per thin-shell level
-    bytes_exchanged_per_shape = (4 * sum(shard_caps[0]) + 12 * shard_caps[1]) if shard_caps else None
+    # what a rank RECEIVES per shape from the all-gathers (every level's gathered buffer + the gradient buffer, minus its own
+    # segment: (world - 1) / world of them; with one rank nothing is exchanged and the figure is what 8 ranks would receive);
+    # round 5 summed zero-filled point-indexed buffers instead (ring all-reduce: 2 x (world - 1) / world of the same buffers);
+    # SURVEY.md section 8e sized the all-gather at <= 5 MB per thin-shell level
+    w_acc = world if world > 1 else 8
+    buffers_bytes = (4 * sum(shard_caps[0]) + 12 * shard_caps[1]) if shard_caps else None
+    bytes_exchanged_per_shape = int(buffers_bytes * (w_acc - 1) / w_acc) if shard_caps else None
     # the same shapes through the fused single-rank fill, timed the same way: what the sharded path costs by construction
     fused_ms = None
     if rank == 0 or world > 1:
@@ -1058,9 +1066,11 @@ def grid_shard_main(a, world, rank):
                                               "a shape that does not fit is repeated inside the timed region") if a.shard_path == "native" else None,
                       "exchange_capacity_points": {"per_level": shard_caps[0], "gradients": shard_caps[1]} if a.shard_path == "native" else None,
                       "exchange_bytes_per_shape": bytes_exchanged_per_shape if a.shard_path == "native" else None,
+                      "exchange_bytes_per_shape_means": (f"bytes a rank receives per shape from the all-gathers at {w_acc} ranks ((world - 1) / world of every gathered buffer); "
+                                                         f"round 5's ring all-reduce of zero-filled buffers of the same capacities moved {int(2 * buffers_bytes * (w_acc - 1) / w_acc) if shard_caps else None}") if a.shard_path == "native" else None,
                       "exchange_buffers_cut_in_timed_region": 0 if a.shard_path == "native" else None,
                       "parallelism": (f"grid-shard x{world}: rank r evaluates tiles r, r + {world}, ... of every level's voxel-ordered list; fixed-capacity value "
-                                      "buffers summed over the ranks (ncclAllReduce over xGMI), 4 B per point per level + 12 B per gradient point")
+                                      "segments of capacity / world points all-gathered (ncclAllGather over xGMI: all_gather_into_tensor), 4 B per point per level + 12 B per gradient point")
                                      if a.shard_path == "native" else
                                      f"grid-shard x{world}: all_gather of 4 B per point per level + 12 B per gradient point over xGMI"},
            "grid_ms_per_shape": {"sharded": shard_ms, "fused_single_rank_fill": fused_ms,

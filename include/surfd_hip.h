@@ -283,11 +283,14 @@ int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_
 
 /* Grid-shard mode (no reference counterpart: the reference fills one grid on one device, meshudf/meshudf.py:123-206; this is the
  * north star's "shard the per-sample 512^3 grid evaluation across the GPUs").  Every one of `world` ranks runs, on its own device,
- *   shard_begin -> per level { shard_level_eval -> [sum the `vals` buffers of the ranks, e.g. ncclAllReduce] -> shard_level_commit }
- *               -> shard_grad_eval -> [sum `ngrads`] -> shard_grad_commit
+ *   shard_begin -> per level { shard_level_eval -> shard_pack -> [ncclAllGather of the ranks' segments] -> shard_level_commit }
+ *               -> shard_grad_eval -> shard_pack -> [all-gather] -> shard_grad_commit
  * with the native decoder: rank r evaluates the 64-point tiles r, r + world, ... of each level's VOXEL-ORDERED point list (the
- * same list on every rank) into vals[point number] and leaves the other entries untouched (zero them first).  All calls are
- * stream-ordered and none reads a count back: list lengths stay on the device, `capacity` (points) bounds what a level may hold —
+ * same list on every rank) into vals[point number]; shard_pack compacts exactly those tiles into the rank's SEGMENT of
+ * capacity / world points (tile t of the list = tile t / world of rank t % world's segment), the segments are all-gathered into
+ * [world][capacity / world] (an all-gather of compact slices — half the bytes of summing zero-filled
+ * point-indexed buffers, and nothing to zero), and shard_level_commit(world) reads point e from the gathered layout.  With
+ * world = 1 there is no pack and no exchange: commit reads the point-indexed buffer.  All calls are stream-ordered and none reads a count back: list lengths stay on the device, `capacity` (points) bounds what a level may hold —
  * a list longer than its buffer is cut and COUNTED on the device (surfd_grid_shard_overflows; the counts themselves are in
  * surfd_grid_get_stats).  The handle tracks the protocol: a call that names another level than the open fill is at, a commit
  * without an evaluation, or a commit with another capacity than its evaluation returns SURFD_ERR_STATE.
@@ -295,10 +298,14 @@ int surfd_grid_grad_commit(surfd_grid *g, const float *ngrads, int64_t n, surfd_
 int surfd_grid_shard_begin(surfd_grid *g, float *udf, float *grads, surfd_stream s);
 int surfd_grid_shard_level_eval(surfd_grid *g, surfd_decoder *d, int sample, int level, int rank, int world, float *vals,
                                 int64_t capacity, surfd_stream s);
-int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, int64_t capacity, surfd_stream s);
+/* this rank's tiles of the step's point-indexed buffer -> its segment [capacity / world] (x 3 floats for the gradient step, named
+ * by level = number of levels); capacity must be whole 64-point tiles of every rank */
+int surfd_grid_shard_pack(surfd_grid *g, int level, int rank, int world, const float *vals, int64_t capacity, float *segment,
+                          surfd_stream s);
+int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, int64_t capacity, int world, surfd_stream s);
 int surfd_grid_shard_grad_eval(surfd_grid *g, surfd_decoder *d, int sample, int rank, int world, float *ngrads, int64_t capacity,
                                surfd_stream s);
-int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, surfd_stream s);
+int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, int world, surfd_stream s);
 /* Exchange buffers that were shorter than the list they carried, over the sharded fills since the last reset (levels and gradient
  * lists; 0 = every grid of that span is complete).  Synchronises the stream (one 8-byte read).  No reference counterpart. */
 int surfd_grid_shard_overflows(surfd_grid *g, int64_t *n, int reset, surfd_stream s);

@@ -96,9 +96,10 @@ _SIGS = {
     "surfd_grid_grad_commit": (C.c_int, [_P, _P, C.c_int64, _P]),
     "surfd_grid_shard_begin": (C.c_int, [_P, _P, _P, _P]),
     "surfd_grid_shard_level_eval": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
-    "surfd_grid_shard_level_commit": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
+    "surfd_grid_shard_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P, _P]),
+    "surfd_grid_shard_level_commit": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, _P]),
     "surfd_grid_shard_grad_eval": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
-    "surfd_grid_shard_grad_commit": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "surfd_grid_shard_grad_commit": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "surfd_grid_shard_overflows": (C.c_int, [_P, c_i64p, C.c_int, _P]),
     "surfd_mc_udf": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "surfd_mc_iso": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),

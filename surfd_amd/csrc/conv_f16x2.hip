@@ -193,21 +193,25 @@ __device__ __forceinline__ f32x4 c2_load_partial(const float *p) {
 #endif
 }
 
-// Experiment, OFF by default (profiles/r05_loop_experiments.md §3): GroupNorm statistics without LDS and without barriers
-// (-DSURFD_C2_GNW=1).  Correct against every golden fixture and 1-2 % faster in the wide form, but NOT bit-stable run to run:
-// with three workgroups per CU the launches of the 4-position level (seven samples per workgroup, split-K 3 / 7 / 8) change
-// the last bits of one sample's statistics in about one evaluation of three (the butterfly itself is exact and stable in
-// isolation — tools/ubench/slot_sum_test.hip — also next to LDS traffic; one workgroup per CU, two per CU, no split-K, the
-// 256-register kernel or a row-after-row order of the same arithmetic are all stable; the cause was not found).  A latent's
-// bits must not depend on timing, so round 4's form below stays the default.  The staging maps thread <-> channel so that
+// GroupNorm statistics in the wave (SURFD_C2_GNW = 1, the default since round 6).  The staging maps thread <-> channel so that
 // every GroupNorm group of a K block sits in ONE wave, in a slot of 2^log2P consecutive lanes (7 channels -> 8 lanes, 14 -> 16,
-// 21 / 28 -> 32, 42 / 56 -> 64; the unused lanes of a slot stage nothing).  A group's sums are then a butterfly over the slot's
-// lanes: DPP for 2, 4, 8 and 16 lanes, v_permlane16_swap / v_permlane32_swap for 32 and 64 — every lane of a slot ends with the same bits (each step adds
-// the same two numbers on both sides).  Round 4's form (thread = channel in tid order, per-(row, channel) means through an LDS
-// exchange area, an 8-lane combine per (row, group), the results through LDS again: two barriers, three where the exchange
-// area aliases the slab) is kept behind -DSURFD_C2_GNW=0.
+// 21 / 28 -> 32, 42 / 56 -> 64; the unused lanes of a slot stage nothing).  A group's sums are a butterfly over the slot's lanes:
+// DPP for 2, 4, 8 and 16 lanes, v_permlane16_swap / v_permlane32_swap for 32 and 64 — every lane of a slot ends with the same
+// bits (each step adds the same two numbers on both sides).  No LDS exchange, no barrier between the operand and the slab.
+//
+// History (profiles/r05_loop_experiments.md section 3, profiles/r06_conv2_instability.md).  Round 5 built this form, found it NOT
+// bit-stable at three workgroups per CU and left it off; the same round saw the LDS-exchange form (SURFD_C2_GNW = 0: per-(row,
+// channel) means through an LDS exchange area, an 8-lane ds_bpermute combine per (row, group), results through LDS again) give
+// timing-dependent wrong results in the VEC = 16 wide kernel.  Round 6 identified what goes wrong in BOTH: one quantity, the
+// 1/sigma of one or two groups of one sample, short by about one lane's term of the second reduction while the mean is right (a
+// regression of the observed error on d out / d (1/sigma_g) explains 100.00 % of it) — a lane of the all-reduce worked with a
+// neighbour's value from before that neighbour's last add.  In this form one wait state between every add and the cross-lane
+// read of its result (SURFD_C2_GNPAD, below) removes it completely (0 differing evaluations in > 400 where every evaluation
+// differed before, two and three workgroups per CU, both column-tile forms, with the weight prefetch compiled into every
+// instantiation); in the LDS-exchange form the same padding does NOT, so that form is retired: it only compiles with
+// -DSURFD_ALLOW_UNSAFE_VARIANTS.
 #ifndef SURFD_C2_GNW
-#define SURFD_C2_GNW 0
+#define SURFD_C2_GNW 1
 #endif
 template <int CTRL>
 __device__ __forceinline__ float c2_dpp(float x) {
@@ -227,7 +231,7 @@ __device__ __forceinline__ float c2_dpp(float x) {
 // padding (s_nop 1 in front of a DPP read, nothing in front of ds_bpermute's data read) assumes the add's result reaches the
 // register file a fixed number of cycles after issue.
 #ifndef SURFD_C2_GNPAD
-#define SURFD_C2_GNPAD 0
+#define SURFD_C2_GNPAD 4           // measured: 1, 2, 4 and 8 are all bit-stable where 0 is not (profiles/r06_conv2_instability.md); 4 costs nothing measurable
 #endif
 __device__ __forceinline__ void c2_gnpad(float &x) {
 #if SURFD_C2_GNPAD > 0
@@ -298,13 +302,14 @@ __device__ __forceinline__ void lds_bar() {
 #ifndef SURFD_C2_PFN
 #define SURFD_C2_PFN 1
 #endif
-// SURFD_C2_PFN_FORMS: 0 (default) = only the lean instantiations (three workgroups per CU; every wide launch of an L = 32 model
-// and the <= 32-position levels of an L = 64 model) carry the request; 1 = every instantiation.  With the request compiled into the
-// VEC = 16 wide kernel (the 64-position level of the L = 64 models: C4 / C5) that kernel's results were no longer bit-stable from
-// run to run and left the 1e-4 bound (one denoiser evaluation at 80 x 64: 1e-3; whole samples of workgroups beyond the first
-// 22 samples' worth) — even with the request pointed at the launch's own first weight line.  profiles/r05_loop_experiments.md §8.
+// SURFD_C2_PFN_FORMS: 1 (default since round 6) = every wide instantiation carries the request; 0 = only the lean ones (three
+// workgroups per CU).  Round 5 compiled it out of the VEC = 16 wide kernel (the 64-position level of the L = 64 models: C4 / C5)
+// because that kernel's results were then not bit-stable and left the 1e-4 bound — which round 6 traced to the GroupNorm
+// statistics of the LDS-exchange form (above), not to the request: with the in-wave statistics the same build is exact and
+// repeatable (profiles/r06_conv2_instability.md) and the 64-position level gets its share of the prefetch (L = 64, two loops of
+// 80: 34.6 -> 33.0 us per evaluation and latent).
 #ifndef SURFD_C2_PFN_FORMS
-#define SURFD_C2_PFN_FORMS 0
+#define SURFD_C2_PFN_FORMS 1
 #endif
 #ifndef SURFD_C2_PFN_N
 #define SURFD_C2_PFN_N 1
@@ -1825,14 +1830,14 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
 #else
 #define C2_CFG_DEVAIDS 0
 #endif
-#define C2_UNSAFE_COUNT ((SURFD_C2_GNW != 0) + (SURFD_C2_PFN_FORMS != 0) + (SURFD_C2_SC1_REDUCE != 0) + (SURFD_C2_LAT_D != 2) + (SURFD_C2_PFN_DMA != 0) + \
+#define C2_UNSAFE_COUNT ((SURFD_C2_GNW != 1) + (SURFD_C2_GNPAD < 1) + (SURFD_C2_SC1_REDUCE != 0) + (SURFD_C2_LAT_D != 2) + (SURFD_C2_PFN_DMA != 0) + \
                          (SURFD_C2_BPIPE == 2) + (C2_CFG_ABLATE != 0) + (C2_CFG_POISON != 0) + (C2_CFG_PROBE != 0) + (C2_CFG_DEVAIDS != 0))
 #if !defined(SURFD_ALLOW_UNSAFE_VARIANTS)
-#if SURFD_C2_GNW != 0
-#error "SURFD_C2_GNW=1 (in-wave GroupNorm) is recorded as NOT bit-stable run to run (profiles/r05_loop_experiments.md section 3); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#if SURFD_C2_GNW != 1
+#error "SURFD_C2_GNW=0 (GroupNorm statistics through the LDS exchange) gives timing-dependent wrong 1/sigma values when workgroups share a CU (profiles/r06_conv2_instability.md); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
 #endif
-#if SURFD_C2_PFN_FORMS != 0
-#error "SURFD_C2_PFN_FORMS=1 (weight prefetch in every instantiation) gave wrong, non-repeatable results at L = 64 (profiles/r05_loop_experiments.md section 8); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
+#if SURFD_C2_GNPAD < 1
+#error "SURFD_C2_GNPAD=0: the in-wave GroupNorm reductions without wait states are NOT bit-stable run to run (profiles/r05_loop_experiments.md section 3, profiles/r06_conv2_instability.md); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
 #endif
 #if SURFD_C2_SC1_REDUCE != 0
 #error "SURFD_C2_SC1_REDUCE=1 reads split-K partials without the acquire: stale L2 copies (profiles/r05_loop_experiments.md section 3); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"

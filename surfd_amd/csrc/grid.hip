@@ -120,7 +120,16 @@ __global__ void emit_points_kernel(PtIO io, float *xyz) {
     }
 }
 
-__global__ void commit_kernel(PtIO io, const float *vals) {
+// grid-shard mode, compact exchange ("all-gather of the level's values"): rank r's 64-point tiles r, r + world,
+// ... travel as ONE contiguous segment of `seg` points per rank (tile t of the list = tile t / world of rank t % world's segment);
+// the gathered buffer is [world][seg].  world <= 1: the buffer is indexed by point number.
+__device__ __forceinline__ long shard_gathered_index(int world, long seg, long e) {
+    if (world <= 1) return e;
+    const long t = e >> 6;
+    return (t % world) * seg + (t / world) * 64 + (e & 63);
+}
+
+__global__ void commit_kernel(PtIO io, const float *vals, int world, long seg) {
     const long n = pt_count(io);
     for (long e0 = blockIdx.x * (long)blockDim.x; e0 < n; e0 += (long)gridDim.x * blockDim.x) {
         const long e = e0 + threadIdx.x;
@@ -128,7 +137,7 @@ __global__ void commit_kernel(PtIO io, const float *vals) {
         int idx = 0;
         if (e < n) {
             idx = pt_voxel(io, e);
-            const float v = vals[e];
+            const float v = vals[shard_gathered_index(world, seg, e)];
             io.grid_udf[idx] = v;
             want = io.grad_list != nullptr && v < io.grad_thr;
         }
@@ -240,11 +249,23 @@ struct LatticeToVoxel {
     LatticeGeom G;
     __device__ __forceinline__ int operator()(int li) const { return lattice_voxel(G, li); }
 };
-__global__ void grad_commit_dev_kernel(const int *list, const int *count, long cap, const float *ng, float *grads) {
+__global__ void grad_commit_dev_kernel(const int *list, const int *count, long cap, const float *ng, float *grads, int world, long seg) {
     const long n = min((long)*count, cap);
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const long idx = list[e];
-        grads[idx * 3 + 0] = ng[e * 3 + 0]; grads[idx * 3 + 1] = ng[e * 3 + 1]; grads[idx * 3 + 2] = ng[e * 3 + 2];
+        const long idx = list[e], ge = shard_gathered_index(world, seg, e);
+        grads[idx * 3 + 0] = ng[ge * 3 + 0]; grads[idx * 3 + 1] = ng[ge * 3 + 1]; grads[idx * 3 + 2] = ng[ge * 3 + 2];
+    }
+}
+
+// this rank's tiles of a point-indexed value buffer -> its contiguous segment (what the all-gather sends): seg[lt * 64 + i] =
+// vals[(lt * world + rank) * 64 + i] for the tiles that exist (n = points of the list, device-side count applied by pt_count)
+__global__ void shard_pack_kernel(PtIO io, int rank, int world, int width, const float *vals, float *seg) {
+    const long n = pt_count(io);
+    for (long le = blockIdx.x * (long)blockDim.x + threadIdx.x;; le += (long)gridDim.x * blockDim.x) {
+        const long e = ((le >> 6) * world + rank) * 64 + (le & 63);
+        if ((((le >> 6) * world + rank) << 6) >= n) break;          // this tile (and every later one of this thread) lies behind the list
+        if (e < n)
+            for (int w = 0; w < width; ++w) seg[le * width + w] = vals[e * width + w];
     }
 }
 
@@ -746,7 +767,7 @@ int surfd_grid_level_commit(surfd_grid *g, int level, const float *values, int64
         PtIO io = eval_io(g, level);
         io.grid_udf = g->cur_udf;
         if (g->cur_grads) { io.grad_list = g->grad_list; io.grad_count = g->counters + CTR_GRAD; io.grad_thr = g->grad_thr; }
-        hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n, 256), 4096)), dim3(256), 0, st, io, values);
+        hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(n, 256), 4096)), dim3(256), 0, st, io, values, 1, 0L);
         LAUNCH_CHECK();
     }
     return refine_level(g, level, g->cur_udf, g->cur_grads != nullptr, st);
@@ -848,10 +869,45 @@ int surfd_grid_shard_level_eval(surfd_grid *g, surfd_decoder *d, int sample, int
     return SURFD_OK;
 }
 
-int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, int64_t capacity, surfd_stream s) {
+static int shard_check_layout(const char *fn, int64_t capacity, int world) {
+    if (world < 1) SURFD_FAIL(SURFD_ERR_ARG, "%s: world must be >= 1", fn);
+    if (world > 1 && capacity % (64 * (int64_t)world) != 0)
+        SURFD_FAIL(SURFD_ERR_ARG, "%s: with %d ranks the capacity (%lld points) must be whole 64-point tiles of every rank", fn, world, (long long)capacity);
+    return SURFD_OK;
+}
+
+// This rank's tiles of the step's point-indexed buffer (what surfd_grid_shard_level_eval / _grad_eval just wrote) -> its segment of
+// capacity / world points: what the all-gather sends.  level = n_levels names the gradient step (3 floats per point).
+int surfd_grid_shard_pack(surfd_grid *g, int level, int rank, int world, const float *vals, int64_t capacity, float *segment, surfd_stream s) {
+    int rc = check_ready(g, "surfd_grid_shard_pack");
+    if (rc) return rc;
+    if (level < 0 || level > g->n_levels || !vals || !segment || capacity < 1 || rank < 0 || rank >= world)
+        SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_pack: bad argument (level %d, rank %d of %d)", level, rank, world);
+    if ((rc = shard_check_layout("surfd_grid_shard_pack", capacity, world))) return rc;
+    if ((rc = shard_expect(g, "surfd_grid_shard_pack", level, capacity, true))) return rc;
+    hipStream_t st = as_stream(s);
+    PtIO io;
+    int width = 1;
+    if (level == g->n_levels) {
+        if (!g->cur_grads) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_pack: the open fill has no gradient step");
+        io = base_io(g);
+        io.mode = PT_LIST; io.list = g->grad_list; io.count_dev = g->counters + CTR_GRAD;
+        width = 3;
+    } else {
+        io = eval_io(g, level);
+    }
+    io.cap = capacity;
+    const long seg = capacity / world;
+    hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(seg, 256), 2048)), dim3(256), 0, st, io, rank, world, width, vals, segment);
+    LAUNCH_CHECK();
+    return SURFD_OK;
+}
+
+int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, int64_t capacity, int world, surfd_stream s) {
     int rc = check_ready(g, "surfd_grid_shard_level_commit");
     if (rc) return rc;
     if (level < 0 || level >= g->n_levels || !vals || capacity < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_level_commit: bad argument");
+    if ((rc = shard_check_layout("surfd_grid_shard_level_commit", capacity, world))) return rc;
     if ((rc = shard_expect(g, "surfd_grid_shard_level_commit", level, capacity, true))) return rc;
     hipStream_t st = as_stream(s);
     PtIO io = eval_io(g, level);
@@ -861,7 +917,7 @@ int surfd_grid_shard_level_commit(surfd_grid *g, int level, const float *vals, i
         hipLaunchKernelGGL(shard_overflow_kernel, dim3(1), dim3(64), 0, st, (const int *)(g->counters + CTR_PARENT + level), 7, (long)capacity, g->overflow);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(upper, 256), 4096)), dim3(256), 0, st, io, vals);
+    hipLaunchKernelGGL(commit_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(upper, 256), 4096)), dim3(256), 0, st, io, vals, world, (long)(capacity / world));
     LAUNCH_CHECK();
     if ((rc = refine_level_ordered(g, level, g->cur_udf, st))) return rc;
     g->shard_level = level + 1; g->shard_evaluated = false; g->shard_cap = 0;
@@ -890,9 +946,10 @@ int surfd_grid_shard_grad_eval(surfd_grid *g, surfd_decoder *d, int sample, int 
     return SURFD_OK;
 }
 
-int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, surfd_stream s) {
+int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t capacity, int world, surfd_stream s) {
     int rc = check_ready(g, "surfd_grid_shard_grad_commit");
     if (rc) return rc;
+    if ((rc = shard_check_layout("surfd_grid_shard_grad_commit", capacity, world))) return rc;
     if (!g->cur_grads) SURFD_FAIL(SURFD_ERR_STATE, "surfd_grid_shard_grad_commit: no gradient buffer was given to surfd_grid_shard_begin");
     if (!ngrads || capacity < 1) SURFD_FAIL(SURFD_ERR_ARG, "surfd_grid_shard_grad_commit: bad argument");
     if ((rc = shard_expect(g, "surfd_grid_shard_grad_commit", g->n_levels, capacity, true))) return rc;
@@ -900,7 +957,7 @@ int surfd_grid_shard_grad_commit(surfd_grid *g, const float *ngrads, int64_t cap
     hipLaunchKernelGGL(shard_overflow_kernel, dim3(1), dim3(64), 0, st, (const int *)(g->counters + CTR_GRAD), 1, (long)capacity, g->overflow);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(grad_commit_dev_kernel, dim3((unsigned)std::min<long>(ceil_div<long>(capacity, 256), 4096)), dim3(256), 0, st,
-                       (const int *)g->grad_list, (const int *)(g->counters + CTR_GRAD), (long)capacity, ngrads, g->cur_grads);
+                       (const int *)g->grad_list, (const int *)(g->counters + CTR_GRAD), (long)capacity, ngrads, g->cur_grads, world, (long)(capacity / world));
     LAUNCH_CHECK();
     g->dense_last = false;
     g->shard_level = -1;

@@ -199,15 +199,17 @@ class GridFiller:
                           adaptive: bool = False):
         """Grid-shard mode, native: ONE shape's grid evaluated by `world` ranks.  Every rank calls this with the
         same latent; rank r runs the native decoder on the 64-point tiles r, r + world, ... of each level's voxel-ordered point
-        list, `exchange(buffer)` sums the per-level value buffers over the ranks in place (default: torch.distributed
-        all_reduce — ncclAllReduce over xGMI with backend "nccl"; world = 1: nothing), and every rank commits the whole level,
-        derives the same next level and ends with the same grid.  Nothing is read back between levels: list lengths stay on the
+        list, compacts them into its SEGMENT of capacity / world points (surfd_grid_shard_pack), `exchange(gathered, own)`
+        all-gathers the ranks' segments (default: parallel.gather_segments — ncclAllGather over xGMI with backend "nccl";
+        world = 1: nothing), and every rank commits the whole level from the gathered layout, derives the same next level and ends
+        with the same grid.  Nothing is read back between levels: list lengths stay on the
         device, a level's exchange buffer holds `capacity` points (an int, one per level as a list, or None = the learned plan /
         the library default 2^24), the gradient buffer `grad_capacity` (12 B each; default 2^21).  A list longer than its buffer
         is cut — and counted on the device (shard_overflows()); with stats=True the counts are read back and a cut raises.
         adaptive=True (one read per shape): the capacities follow the field — every fill re-plans them from its own counts
         (plan_shard_capacities) and a fill that was cut is repeated with buffers sized from what it needed; identical on every
-        rank because the counts are.  `self.shard_bytes_exchanged` sums the bytes handed to `exchange`.
+        rank because the counts are.  `self.shard_bytes_exchanged` sums the bytes a rank RECEIVES from the others
+        ((world - 1) / world of every gathered buffer).
         simulate_ranks=True (tests on one device): this process plays every rank in turn — the sharding logic without a second GPU.
         The result equals the fused single-rank fill bit for bit."""
         native = getattr(udf_func, "_surfd_native", None)
@@ -226,40 +228,55 @@ class GridFiller:
             udf, grads = out
         st = N.stream()
         if exchange is None and world > 1 and not simulate_ranks:
-            from .parallel import sum_over_ranks
-            exchange = sum_over_ranks
+            from .parallel import gather_segments
+            exchange = gather_segments
         ranks = range(world) if simulate_ranks else (rank,)
         if not hasattr(self, "shard_bytes_exchanged"):
             self.shard_bytes_exchanged = 0
         for attempt in range(3):
             caps, gcap = self.shard_capacities(capacity, grad_capacity)
+            if world > 1:                         # a rank's segment is whole 64-point tiles: capacity / world
+                unit = 64 * world
+                caps = [((c + unit - 1) // unit) * unit for c in caps]
+                gcap = ((gcap + unit - 1) // unit) * unit
             need = max(max(caps), 3 * gcap if grads is not None else 0)
             buf = getattr(self, "_shard_buf", None)
             if buf is None or buf.numel() < need or buf.device != dev:
                 buf = self._shard_buf = torch.empty(need, device=dev, dtype=torch.float32)
+            gat = own = None
+            if world > 1:                         # the gathered layout [world][segment] and this rank's segment
+                gat = getattr(self, "_shard_gat", None)
+                if gat is None or gat.numel() < need or gat.device != dev:
+                    gat = self._shard_gat = torch.empty(need, device=dev, dtype=torch.float32)
+                own = getattr(self, "_shard_own", None)
+                if own is None or own.numel() < need // world or own.device != dev:
+                    own = self._shard_own = torch.empty(need // world, device=dev, dtype=torch.float32)
             N.check(L.surfd_grid_shard_begin(h, N.ptr(udf), N.ptr(grads), st))
+
+            def exchange_step(level, vals, cap, width):
+                """this process's rank(s): tiles -> segment(s) -> the gathered buffer every rank commits from"""
+                seg = cap // world * width
+                for r in ranks:
+                    dst = gat[r * seg:(r + 1) * seg] if simulate_ranks else own[:seg]
+                    N.check(L.surfd_grid_shard_pack(h, level, r, world, N.ptr(vals), cap, N.ptr(dst), st))
+                if exchange is not None:
+                    exchange(gat[:world * seg], own[:seg])
+                self.shard_bytes_exchanged += 4 * seg * (world - 1)      # received from the other ranks (also when one process plays them)
+                return gat[:world * seg]
+
+            nl = len(caps)
             for level, cap in enumerate(caps):
                 vals = buf[:cap]
-                if world > 1:
-                    vals.zero_()                  # the sum over the ranks IS the exchange: entries of other ranks' tiles must be zero here
                 for r in ranks:
                     N.check(L.surfd_grid_shard_level_eval(h, dh, smp, level, r, world, N.ptr(vals), cap, st))
-                if exchange is not None:
-                    exchange(vals)
-                if world > 1:
-                    self.shard_bytes_exchanged += 4 * cap          # what the collective moves per rank (also when one process plays the ranks)
-                N.check(L.surfd_grid_shard_level_commit(h, level, N.ptr(vals), cap, st))
+                src = exchange_step(level, vals, cap, 1) if world > 1 else vals
+                N.check(L.surfd_grid_shard_level_commit(h, level, N.ptr(src), cap, world, st))
             if grads is not None:
                 ng = buf[:3 * gcap]
-                if world > 1:
-                    ng.zero_()
                 for r in ranks:
                     N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, r, world, N.ptr(ng), gcap, st))
-                if exchange is not None:
-                    exchange(ng)
-                if world > 1:
-                    self.shard_bytes_exchanged += 12 * gcap
-                N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(ng), gcap, st))
+                src = exchange_step(nl, ng, gcap, 3) if world > 1 else ng
+                N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(src), gcap, world, st))
             if not (stats or adaptive):
                 break
             self.last_stats = self._stats()

@@ -62,19 +62,29 @@ def gather_latents(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
     return res.to(local.device) if via_host else res
 
 
-def sum_over_ranks(buf: torch.Tensor) -> None:
-    """In-place sum of a buffer over the ranks (grid-shard mode: every entry is non-zero on exactly one rank, so the sum IS the
-    exchange — x + 0 is exact).  ncclAllReduce over xGMI with backend "nccl"; gloo moves host memory, device tensors take a round
-    trip through the host there (CPU tests; ranks sharing one GPU)."""
+def gather_segments(out: torch.Tensor, own: torch.Tensor) -> None:
+    """Grid-shard mode's exchange: every rank contributes its compact segment `own` [seg] and receives all of
+    them, rank-major, in `out` [world * seg] — ncclAllGather over xGMI with backend "nccl" (all_gather_into_tensor: one
+    collective, no zero-filled padding, (world - 1) / world x the buffer received per rank, i.e. half of what summing
+    point-indexed buffers with a ring all-reduce moved); gloo moves host memory, device tensors take a round trip through the host
+    there (CPU tests; ranks sharing one GPU)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        out.copy_(own)
         return
-    if buf.is_cuda and dist.get_backend() == "gloo":
-        h = buf.cpu()
-        dist.all_reduce(h)
-        buf.copy_(h)
+    world = dist.get_world_size()
+    assert out.numel() == world * own.numel(), (out.numel(), world, own.numel())
+    if own.is_cuda and dist.get_backend() == "gloo":
+        h = own.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h)
+        out.copy_(torch.cat(parts))
+    elif dist.get_backend() == "gloo":
+        parts = [torch.empty_like(own) for _ in range(world)]
+        dist.all_gather(parts, own)
+        out.copy_(torch.cat(parts))
     else:
-        dist.all_reduce(buf)
+        dist.all_gather_into_tensor(out, own)
 
 
 def sample_sharded(diffusion, model, total: int, latent_len: int, sampler: str = "ddpm", seed: int = 1234,

@@ -117,3 +117,29 @@ def test_rank_cpu_placement(bench):
     assert bench.rank_cpu_slice(odd, 2, 1) == [9, 10, 11, 12, 13]
     assert bench._cpu_ranges(odd) == "0-3,8-13" and bench._cpu_ranges([5]) == "5"
     assert bench.MAX_CLOCK_GHZ == 2.4
+
+
+def test_latency_form_roofline_and_build_flags(bench):
+    """the driver line carries the latency form's fraction of its HBM roof (strict_c3.roofline), the fabric-side
+    over-fetch of the wide loops (roofline_loop.traffic_over_algorithmic) and the library's compile-time configuration
+    (config.build_flags).  The arithmetic, on round 5's measured 1.36 s per 1000-step request at 8 latents:"""
+    r = bench.latency_form_roofline(1.36, 1000, 8, 32, "f16x2")
+    assert r["bound"] == "hbm" and r["roof_us_hbm"] == pytest.approx(69.16, rel=1e-3) and r["us_per_evaluation"] == pytest.approx(1360.0)
+    assert r["frac"] == pytest.approx(69.16 / 1360.0, rel=1e-3) and r["achieved"] == pytest.approx(0.553294340 / 1.36e-3, rel=1e-6)       # ~407 GB/s of 8 000
+    cfg = bench.build_config()
+    assert "unsafe_variants=0" in cfg.split() and "C2_GNW=1" in cfg.split() and any(kv.startswith("C2_GNPAD=") for kv in cfg.split())
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for field in ('"roofline": latency_form_roofline(', '"traffic_over_algorithmic"', '"build_flags": build_config()'):
+        assert field in src, field
+
+
+def test_committed_driver_line_carries_the_round_6_fields():
+    """the newest committed line of the driver's command (profiles/rNN_bench_driver_cmd.json, round 6 on)"""
+    import glob
+    import json
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_driver_cmd.json")))[-1]
+    if int(os.path.basename(newest)[1:3]) < 6:
+        pytest.skip("no round-6 driver line committed yet")
+    d = json.load(open(newest))
+    assert 0 < d["strict_c3"]["roofline"]["frac"] < 1 and d["strict_c3"]["roofline"]["bound"] == "hbm"
+    assert "traffic_over_algorithmic" in d["roofline_loop"] and "unsafe_variants=0" in d["config"]["build_flags"]

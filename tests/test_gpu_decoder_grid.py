@@ -830,18 +830,22 @@ def test_grid_shard_protocol_state_is_checked():
     cap, gcap = 32 ** 3, 1 << 18                            # gradient capacity = every voxel of the 64^3 grid
     assert L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st) == ERR_STATE          # nothing open
     N.check(L.surfd_grid_shard_begin(h, N.ptr(udf), N.ptr(grads), st))
-    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st) == ERR_STATE                       # commit before eval
+    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, 1, st) == ERR_STATE                       # commit before eval
     assert L.surfd_grid_shard_level_eval(h, dh, smp, 1, 0, 1, N.ptr(buf), 1 << 18, st) == ERR_STATE     # level 1 before level 0
     assert L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), gcap, st) == ERR_STATE            # gradients before the levels
+    seg = torch.empty(3 << 18, device="cuda")
+    assert L.surfd_grid_shard_pack(h, 0, 0, 2, N.ptr(buf), cap, N.ptr(seg), st) == ERR_STATE               # pack before the evaluation
     N.check(L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st))
-    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap - 64, st) == ERR_STATE                  # another capacity than the eval
-    N.check(L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st))
-    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, st) == ERR_STATE                       # level 0 is closed
+    assert L.surfd_grid_shard_pack(h, 0, 0, 3, N.ptr(buf), cap, N.ptr(seg), st) == -1                      # 32^3 points are not whole tiles of 3 ranks (ERR_ARG)
+    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, 3, st) == -1
+    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap - 64, 1, st) == ERR_STATE                  # another capacity than the eval
+    N.check(L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, 1, st))
+    assert L.surfd_grid_shard_level_commit(h, 0, N.ptr(buf), cap, 1, st) == ERR_STATE                       # level 0 is closed
     N.check(L.surfd_grid_shard_level_eval(h, dh, smp, 1, 0, 1, N.ptr(buf), 1 << 18, st))
-    N.check(L.surfd_grid_shard_level_commit(h, 1, N.ptr(buf), 1 << 18, st))
-    assert L.surfd_grid_shard_grad_commit(h, N.ptr(buf), gcap, st) == ERR_STATE                          # gradient commit before its eval
+    N.check(L.surfd_grid_shard_level_commit(h, 1, N.ptr(buf), 1 << 18, 1, st))
+    assert L.surfd_grid_shard_grad_commit(h, N.ptr(buf), gcap, 1, st) == ERR_STATE                          # gradient commit before its eval
     N.check(L.surfd_grid_shard_grad_eval(h, dh, smp, 0, 1, N.ptr(buf), gcap, st))
-    N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(buf), gcap, st))
+    N.check(L.surfd_grid_shard_grad_commit(h, N.ptr(buf), gcap, 1, st))
     assert L.surfd_grid_shard_level_eval(h, dh, smp, 0, 0, 1, N.ptr(buf), cap, st) == ERR_STATE          # the fill is closed
     # what the protocol produced is the fused fill's grid
     a, b = GridFiller(64).fill_grid(f, 2 ** 16)
@@ -889,3 +893,25 @@ def test_native_sharded_fill_two_ranks_over_gloo_on_one_gpu():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="grid-shard over RCCL needs two GPUs (1-GPU boxes skip; the gloo variant above covers the logic)")
 def test_native_sharded_fill_two_gpus_over_rccl():
     _run_native_shard("nccl")
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
+def test_decoder_kernels_are_bit_stable_run_to_run(precision):
+    """the forward kernel (8-wave in f16x2) and the forward + reverse-sweep kernel, 40 evaluations of the same 100 000
+    points each (all CUs, several tiles per persistent workgroup): identical bits."""
+    dec, _ = _decoder(32)
+    dec.set_precision(precision)
+    try:
+        g = torch.Generator().manual_seed(31)
+        lat = (torch.randn(1, 32, generator=g) * 0.8).cuda()
+        pts = (torch.rand(100_000, 3, generator=g) * 2 - 1).cuda()
+        dec.bind_latents(lat)
+        u0 = dec.udf(pts, 0).clone()
+        v0, n0 = (a.clone() for a in dec.udf_and_ngrad(pts, 0))
+        for run in range(1, 40):
+            assert torch.equal(dec.udf(pts, 0), u0), run
+            v, n = dec.udf_and_ngrad(pts, 0)
+            assert torch.equal(v, v0) and torch.equal(n, n0), run
+        assert dec.saturation_count() == 0
+    finally:
+        dec.set_precision("f16x2")

@@ -780,3 +780,62 @@ def test_wide_form_conditioned_latent_does_not_depend_on_batch_width():
         assert torch.isfinite(whole).all() and model.saturation_count() == 0
     finally:
         model.set_wide(0)
+
+
+# ---- run-to-run bit stability of every instantiation -------------------------------------------------------
+# Round 5's two instabilities (profiles/r06_conv2_instability.md) gave a DIFFERENT wrong result in most evaluations: 40 evaluations
+# of the same input through the same handle see them with certainty, and cost a fraction of a second per case.
+_STABILITY_CASES = [
+    # (B, L, wide design batch): which conv2_kernel instantiations an evaluation launches
+    (8, 32, 0),       # latency form, VEC = 8 (what sample/generate_* runs)
+    (8, 64, 0),       # latency form, VEC = 16 at the 64-position level
+    (80, 32, 80),     # lean wide form: three workgroups per CU (the bench's loops)
+    (53, 32, 80),     # the same with a ragged last batch chunk
+    (160, 32, 160),   # two column tiles per wave (NT2)
+    (80, 64, 32),     # VEC = 16 wide form (two workgroups per CU) at the 64-position level + lean form below it: round 5's failing case
+    (40, 64, 80),
+    (24, 64, 32),     # the smallest batch at which round 5's build went wrong
+]
+
+
+@pytest.mark.parametrize("B,L,wide", _STABILITY_CASES)
+def test_denoiser_evaluation_is_bit_stable_run_to_run(B, L, wide):
+    model, _, _ = _model("no_cond")
+    model.set_wide(wide)
+    try:
+        g = torch.Generator().manual_seed(7 * B + L)
+        x = torch.randn(B, 1, L, generator=g).cuda(); t = torch.randint(0, 1000, (B,), generator=g).cuda()
+        first = model(x, t, y={}).clone()
+        for run in range(1, 40):
+            out = model(x, t, y={})
+            if not torch.equal(out, first):
+                d = (out - first).abs()
+                bad = sorted(set(torch.nonzero(d.flatten(1).sum(1)).flatten().tolist()))
+                raise AssertionError(f"evaluation {run} differs from evaluation 0: max |d| = {float(d.max()):.3e} in samples {bad[:16]}")
+        # and it is the right result: every sample against the exact-fp32 kernels
+        model.set_precision("fp32")
+        try:
+            exact = model(x, t, y={}).clone()
+        finally:
+            model.set_precision("f16x2")
+        assert float((first - exact).abs().max()) <= 1e-4
+        assert model.saturation_count() == 0
+    finally:
+        model.set_wide(0)
+
+
+@pytest.mark.parametrize("B,L,wide", [(8, 32, 0), (80, 32, 80), (8, 64, 0), (80, 64, 80)])
+def test_fused_loop_is_bit_stable_run_to_run(B, L, wide):
+    """The head convolution inside the graph-replayed loop (the LF instantiations: posterior update in the epilogue) and 20
+    consecutive evaluations feeding each other: the same noise gives the same latents, 8 times."""
+    model, diff, _ = _model("no_cond", "ddim20")
+    model.set_wide(wide)
+    try:
+        noise = synth.synth_noise_batch(diff.num_timesteps, 0, B, L).cuda()
+        first = diff.ddim_sample_loop(model, (B, 1, L), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise, fused=True).clone()
+        for run in range(1, 8):
+            out = diff.ddim_sample_loop(model, (B, 1, L), clip_denoised=False, model_kwargs={"y": {}}, noise_stream=noise, fused=True)
+            assert torch.equal(out, first), f"loop {run}: max |d| = {float((out - first).abs().max()):.3e}"
+        assert torch.isfinite(first).all()
+    finally:
+        model.set_wide(0)

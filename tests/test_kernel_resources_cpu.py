@@ -60,10 +60,10 @@ def test_lean_conv_kernel_fits_three_workgroups_per_cu(meta):
     scratch (the build for four — 128 registers — spills 63 and measured 30 % slower), <= 112 SGPRs (the hardware admits
     floor(800 / (ceil(sgpr / 16) * 16 + 16)) blocks of 256 threads per CU)."""
     k = _one(meta, "void surfd::conv2_kernel<8, false, true, true, false, false>")
-    # round 5: ONE spilled register — the word of the next layer's weights every thread requests at kernel start (weight prefetch
-    # ahead), parked until the empty statement that "uses" it at the very end; read back from the code object: one scratch store
-    # in the prologue, one load in front of s_endpgm, nothing inside the K loop
-    assert k[".vgpr_spill_count"] <= 1 and k[".private_segment_fixed_size"] <= 8
+    # round 5 allowed ONE spilled register here (the word of the weight prefetch parked to the kernel's end — a private scratch
+    # segment for every dispatch of the hot kernel, ADVICE r5); with the in-wave GroupNorm statistics of round 6 the registers the
+    # LDS exchange needed are free and nothing spills
+    assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0
     assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 168
     assert k[".sgpr_count"] <= 112
 

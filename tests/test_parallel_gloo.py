@@ -73,19 +73,26 @@ def _grid_run(N=64):
 
 
 def _tile_exchange(rank, world, n=1000, cap=2048, tile=64):
-    """The exchange protocol of the NATIVE grid-shard path (surfd_grid_shard_level_eval / GridFiller.fill_grid_sharded) on the
-    host: rank r fills the 64-point tiles r, r + world, ... of a zeroed fixed-capacity buffer indexed by point number, the
-    buffers are summed over the ranks (parallel.sum_over_ranks) — every entry is non-zero on exactly one rank, so the sum is the
-    gather, bit for bit, and entries beyond the level's length stay zero."""
+    """The exchange protocol of the NATIVE grid-shard path (surfd_grid_shard_level_eval / _pack / _level_commit behind
+    GridFiller.fill_grid_sharded) on the host: rank r evaluates the 64-point tiles r, r + world, ... of the level's list, compacts
+    them into its segment of cap / world points (tile t of the list = tile t // world of rank t % world's segment), the segments
+    are all-gathered rank-major (parallel.gather_segments), and every rank reads point e of the level at
+    (t % world) * seg + (t // world) * 64 + e % 64.  No zero-fill, no sum: what arrives is the level, bit for bit."""
     from oracle import gridfiller as ogrid
-    from surfd_amd.parallel import sum_over_ranks
+    from surfd_amd.parallel import gather_segments
+    assert cap % (tile * world) == 0
+    seg = cap // world
     pts = torch.rand(n, 3, generator=torch.Generator().manual_seed(5)) * 2 - 1       # the same "level" on every rank
-    vals = torch.zeros(cap)
+    own = torch.full((seg,), float("nan"))                                           # entries behind the list are never read
     for t in range(rank, -(-n // tile), world):
         lo, hi = t * tile, min((t + 1) * tile, n)
-        vals[lo:hi] = ogrid.analytic_field(pts[lo:hi])
-    sum_over_ranks(vals)
-    return vals.clone(), ogrid.analytic_field(pts)
+        own[(t // world) * tile:(t // world) * tile + hi - lo] = ogrid.analytic_field(pts[lo:hi])
+    gathered = torch.empty(cap)
+    gather_segments(gathered, own)
+    e = torch.arange(n)
+    t = e // tile
+    level = gathered[(t % world) * seg + (t // world) * tile + e % tile]
+    return level.clone(), ogrid.analytic_field(pts)
 
 
 def _worker(rank, world, port, out):
@@ -119,6 +126,6 @@ def test_sharded_equals_single_process():
         # grid-shard mode: every rank ends with the single-process grid, bit for bit
         assert torch.equal(out[r][4], gu1) and out[r][6] == gstats1["fwd_per_level"]
         assert torch.equal(out[r][5], gg1)
-        # native grid-shard exchange: interleaved tiles + sum over the ranks == the whole level, the padding stays zero
+        # native grid-shard exchange: interleaved tiles -> compact segments -> all-gather == the whole level
         vals, want = out[r][7]
-        assert torch.equal(vals[:want.shape[0]], want) and not vals[want.shape[0]:].any()
+        assert torch.equal(vals, want)
