@@ -487,14 +487,13 @@ def test_grid_512_properties(D):
     #      "not close" value (>= 0.0398), so the parent was evaluated, was close, and the voxel was evaluated at the 512 level.
     thr256 = float(torch.tensor(ogrid.refine_threshold(256), dtype=torch.float32))
     g2 = torch.Generator().manual_seed(23)
-    cand = torch.randint(0, 512 ** 3, (4_000_000,), generator=g2).cuda()
-    ci, cj, ck = cand // (512 * 512), (cand // 512) % 512, cand % 512
-    odd = ((ci | cj | ck) & 1) == 1
-    parent = ((ci & ~1) * 512 + (cj & ~1)) * 512 + (ck & ~1)
     flat = udf.reshape(-1)
-    at512 = cand[odd & (flat[parent] < thr256)]
-    assert len(at512) >= 4096, len(at512)
-    at512 = at512[:4096].cpu()
+    par = torch.nonzero(udf[::2, ::2, ::2].reshape(-1) < thr256).flatten()            # 256-level lattice points whose block was refined
+    assert len(par) >= 64, len(par)
+    pick = par[torch.randint(0, len(par), (4096,), generator=g2).cuda()]
+    child = torch.randint(1, 8, (4096,), generator=g2).cuda()                         # one of the 7 voxels of the block that are new at the 512 level
+    pi, pj, pk = pick // (256 * 256), (pick // 256) % 256, pick % 256
+    at512 = (((2 * pi + ((child >> 2) & 1)) * 512 + (2 * pj + ((child >> 1) & 1))) * 512 + (2 * pk + (child & 1))).cpu()
     gflat = grads.reshape(-1, 3)
     gcand = torch.nonzero(has.reshape(-1)).flatten()
     gsel = gcand[torch.randperm(len(gcand), generator=g2)[:4096].cuda()].cpu()
