@@ -786,7 +786,8 @@ def test_native_sharded_fill_equals_fused_fill(world, precision):
         gc.fill_grid_sharded(f, world=world, simulate_ranks=True, stats=False, capacity=1 << 21)
         assert gc.shard_overflows(reset=False) == 0
         st2 = gc._stats()["fwd_per_level"]
-        gc.fill_grid_sharded(f, world=world, simulate_ranks=True, stats=False, capacity=[st2[0], st2[1], st2[2] - 64])
+        unit = 64 * world                                          # capacities are whole 64-point tiles of every rank (rounded UP by the filler)
+        gc.fill_grid_sharded(f, world=world, simulate_ranks=True, stats=False, capacity=[st2[0], st2[1], (st2[2] // unit - 1) * unit])
         assert gc.shard_overflows() == 1 and gc.shard_overflows() == 0                   # read + reset
         # adaptive capacities: every fill plans the next one's buffers from its own counts (a thin level travels as what it
         # holds, not as 2^24 points); a plan that turns out too small is noticed and the fill repeated — same bits either way
