@@ -97,7 +97,7 @@ struct Conv2Args {
     int pf_ntiles, pf_KS16, pf_KS, pf_G, pf_nblk0, pf_it0, pf_nch, pf_it1;
     int pf_log2tpg, pf_log2bps, pf_log2lpb;   // tiles per group (1 / 4), K blocks per slice and 128-byte lines per K block, rounded up to powers of two
     unsigned pf_magic_ks;
-    int off_pf;            // byte offset of 256 bytes of LDS nobody reads: where the requested words land (SURFD_C2_PFN_DMA)
+    int off_pf;            // unused since round 6 (was: landing area of an LDS-DMA form of the request); kept so that the argument block keeps its eight lines
 };
 
 #ifndef SURFD_C2_EPI_LATE
@@ -170,28 +170,10 @@ __device__ __forceinline__ void c2_kernarg_prefetch() {
 #endif
 }
 
-// Experiment, OFF (the macro is the record; profiles/r05_loop_experiments.md): split-K partial tiles read with sc1 loads instead
-// of plain loads behind the last arriver's agent-scope acquire (buffer_inv sc1).  An sc1 load bypasses this CU's L1 — but the
-// partial buffer is re-used by every launch, and a copy of the line from an EARLIER launch's reduction can still sit in this
-// XCD's L2: with two loops and the decoder in flight the sequential and the pipelined run of
-// test_batch_pipeline_matches_sequential stopped agreeing bit for bit.  It bought nothing measurable either (2 x 80 latents
-// 3.31 vs 3.35 ms per evaluation, latency form 1.421 vs 1.413).  The acquire stays.
-#ifndef SURFD_C2_SC1_REDUCE
-#define SURFD_C2_SC1_REDUCE 0
-#endif
-__device__ __forceinline__ f32x4 c2_load_partial(const float *p) {
-#if SURFD_C2_SC1_REDUCE
-    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    f32x4 r;
-    r[0] = __uint_as_float((unsigned)a); r[1] = __uint_as_float((unsigned)(a >> 32));
-    r[2] = __uint_as_float((unsigned)b); r[3] = __uint_as_float((unsigned)(b >> 32));
-    return r;
-#else
-    return *reinterpret_cast<const f32x4 *>(p);
-#endif
-}
+// split-K partial tiles are read with plain loads behind the last arriver's agent-scope acquire (round 5 tried sc1 loads without
+// the acquire: an sc1 load bypasses this CU's L1 but not a copy of the line an EARLIER launch's reduction left in this XCD's L2 —
+// the sequential and the pipelined run stopped agreeing bit for bit; removed in round 6, profiles/r05_loop_experiments.md section 3)
+__device__ __forceinline__ f32x4 c2_load_partial(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
 // GroupNorm statistics in the wave (SURFD_C2_GNW = 1, the default since round 6).  The staging maps thread <-> channel so that
 // every GroupNorm group of a K block sits in ONE wave, in a slot of 2^log2P consecutive lanes (7 channels -> 8 lanes, 14 -> 16,
@@ -219,11 +201,6 @@ __device__ __forceinline__ float c2_dpp(float x) {
 }
 // N independent sums, step by step (the N chains of dependent DPP / bpermute operations overlap); x must be zero in the lanes
 // of a slot that hold no channel
-#if defined(SURFD_C2_GNW_NOPK)         // developer aid: every chain opaque to the vectoriser (no v_pk_add_f32 over two chains)
-#define C2_OPAQUE(v) asm volatile("" : "+v"(v))
-#else
-#define C2_OPAQUE(v) do { } while (0)
-#endif
 // SURFD_C2_GNPAD=n (round 6): n wait states between every add of the GroupNorm reductions and the cross-lane read (DPP,
 // ds_bpermute, v_permlane*_swap) of its result.  The statistics are the one quantity that goes wrong in the timing-dependent
 // failures of round 5 (profiles/r06_conv2_instability.md: 1/sigma of one or two groups short by about one lane's term, mean
@@ -257,27 +234,27 @@ __device__ __forceinline__ void c2_slot_sum(float (&x)[N], int log2P) {
 #endif
     if (log2P > 0) {         // quad_perm [1,0,3,2]: lane ^ 1
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0xB1>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0xB1>(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 1) {         // quad_perm [2,3,0,1]: lane ^ 2
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x4E>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x4E>(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 2) {         // row_half_mirror: the other quad of the 8
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x141>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x141>(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 3) {         // row_mirror: the other half of the 16
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x140>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] += c2_dpp<0x140>(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 4) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<16>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<16>(x[i]); c2_gnpad(x[i]); }
     }
     if (log2P > 5) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<32>(x[i]); C2_OPAQUE(x[i]); c2_gnpad(x[i]); }
+        for (int i = 0; i < N; ++i) { x[i] = c2_swap_sum<32>(x[i]); c2_gnpad(x[i]); }
     }
 }
 
@@ -315,14 +292,9 @@ __device__ __forceinline__ void lds_bar() {
 #define SURFD_C2_PFN_N 1
 #endif
 constexpr int C2_PFN_N = SURFD_C2_PFN_N;
-// SURFD_C2_PFN_DMA=1 (experiment, off): the request as an LDS-DMA load instead of an ordinary one — no destination register, so
-// the one register the lean form spills for it (and the wait that spill implies) would go away.  Measured SLOWER (2 x 80 latents
-// 3.17 against 3.08-3.14 ms per evaluation), and M0's 16-bit LDS base wraps in the two-per-CU forms (74 KB of LDS: the word
-// landed in the slab).
-#ifndef SURFD_C2_PFN_DMA
-#define SURFD_C2_PFN_DMA 0
-#endif
-__device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, unsigned (&sink)[C2_PFN_N], unsigned lds_dst) {
+// (Round 5 also tried the request as an LDS-DMA load — no destination register: slower, and M0's 16-bit LDS base wraps in the
+// two-per-CU forms — and developer variants without the load / with the word awaited at once; removed in round 6.)
+__device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, unsigned (&sink)[C2_PFN_N]) {
 #if SURFD_C2_PFN
     const int bid = blockIdx.x, nwg = gridDim.x;
     const int x = bid & 7, i = bid >> 3, nx = (nwg + 7 - x) >> 3;            // this workgroup is number i of nx on XCD x
@@ -353,38 +325,8 @@ __device__ __forceinline__ void c2_prefetch_next(const Conv2Args &A, int tid, un
             off[k] = ok ? (((long)tile * A.pf_KS16 + k16) * 2048 + (long)l * 128) : 0;
         }
     }
-#if SURFD_C2_PFN_DMA
-    // The request as an LDS-DMA load (global_load_lds_dword: the word lands in 256 bytes of LDS nobody reads — no destination
-    // register).  As an ordinary load the word needed a register from here to the end of a kernel that has none to spare: the
-    // compiler spilled it, and a spill is a store of the LOADED value — an s_waitcnt vmcnt(0) right here, in front of the wait
-    // for the operand (read back from the code object).  The compiler does not count this request; it is the youngest when
-    // issued and long complete when the ring's counted waits begin.  M0 (the DMA's LDS base) is set and restored inside the
-    // statement.
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
-#pragma unroll
-    for (int k = 0; k < C2_PFN_N; ++k) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(w + off[k]), "s"(dst) : "memory");
-        sink[k] = 0u;
-    }
-#elif defined(SURFD_C2_PFN_NOLOAD)      // developer aid: the index arithmetic without the memory request
-#pragma unroll
-    for (int k = 0; k < C2_PFN_N; ++k) sink[k] = (unsigned)off[k] ^ (unsigned)(size_t)w;
-#else
 #pragma unroll
     for (int k = 0; k < C2_PFN_N; ++k) sink[k] = *reinterpret_cast<const unsigned *>(w + off[k]);
-#endif
-#if defined(SURFD_C2_PFN_EARLYUSE)      // developer aid: the requested word is awaited right here instead of at the kernel's end
-    {
-        unsigned used = 0u;
-#pragma unroll
-        for (int k = 0; k < C2_PFN_N; ++k) used |= sink[k];
-        asm volatile("" :: "v"(used));
-#pragma unroll
-        for (int k = 0; k < C2_PFN_N; ++k) sink[k] = 0u;
-    }
-#endif
 #else
 #pragma unroll
     for (int k = 0; k < C2_PFN_N; ++k) sink[k] = 0u;
@@ -702,10 +644,6 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         ga = A.seg[s].gamma[cg]; be = A.seg[s].beta[cg];      // segments without GroupNorm point these at the bias vector
     };
 
-#if defined(SURFD_C2_DBG_CLEARLDS)     // developer aid: nothing a previous workgroup left in LDS can be read
-    for (int e = tid; e < (int)(2 * PLANE / 2); e += 256) reinterpret_cast<unsigned *>(lds_raw)[e] = 0u;
-    lds_bar();
-#endif
     int ch = kz;
     WS cur = make_ws(ch);
     f32x4 v[VEC];
@@ -714,7 +652,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #pragma unroll
     for (int d = 0; d < C2_D; ++d) load_group(ring[d], cur.base, cur.it_beg + d * C2_U, cur.it_end - 1);
     unsigned pf_sink[C2_PFN_N];
-    if constexpr (SURFD_C2_PFN_FORMS || LEAN) c2_prefetch_next(A, tid, pf_sink, (unsigned)(size_t)(lds_raw + A.off_pf));     // the next convolution's weights, towards this XCD's L2
+    if constexpr (SURFD_C2_PFN_FORMS || LEAN) c2_prefetch_next(A, tid, pf_sink);     // the next convolution's weights, towards this XCD's L2
     else {
 #pragma unroll
         for (int k = 0; k < C2_PFN_N; ++k) pf_sink[k] = 0u;
@@ -795,9 +733,6 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                 C2_PROBE_ADD(0, h);
             }
 #endif
-#if defined(SURFD_C2_DBG_WAITALL)      // developer aid: every outstanding load has landed before the operand is touched
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
             if (A.seg[s].gn) {
                 const int gs = A.seg[s].gs;
                 // ---- GroupNorm statistics, two-pass, in registers first: per (batch row, channel) mean and M2 over the
@@ -843,22 +778,17 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                 // S = float4 per row (compile time per branch of the wave-uniform dispatch below): the VEC / S rows of this thread
                 // go through the two butterflies together — rows past the batch chunk (clamped re-reads of the last row) included,
                 // their results are never used — and every float4 of a row receives the row's result by static index
-#if defined(SURFD_C2_GNW_LIVEONLY)     // developer aid: rows past the batch chunk contribute zeros
-#define C2_ROW_LIVE(i) (rowbase + (i) < nb)
-#else
-#define C2_ROW_LIVE(i) true
-#endif
                 auto group_stats = [&](auto stride) {
                     constexpr int S = decltype(stride)::value, NR = VEC / S;
                     float a[NR], gm[NR];
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) a[i] = (cok && C2_ROW_LIVE(i)) ? rs[i * S] : 0.f;
+                    for (int i = 0; i < NR; ++i) a[i] = cok ? rs[i * S] : 0.f;
                     c2_slot_sum<NR>(a, lp);
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         gm[i] = a[i] * inv_gs;
                         const float d = rs[i * S] - gm[i];
-                        a[i] = (cok && C2_ROW_LIVE(i)) ? rm2[i * S] + flin * (d * d) : 0.f;
+                        a[i] = cok ? rm2[i * S] + flin * (d * d) : 0.f;
                     }
                     c2_slot_sum<NR>(a, lp);
 #pragma unroll
@@ -868,32 +798,11 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                         for (int m = 0; m < S; ++m) { gmr[i * S + m] = gm[i]; gscr[i * S + m] = sc; }
                     }
                 };
-#if defined(SURFD_C2_GNW_ROWWISE)      // developer aid: one row after the other, dead rows skipped (the first form of this code)
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    gmr[j] = 0.f; gscr[j] = 0.f;
-                    if ((j & (vpr - 1)) == 0 && rowbase + (j >> lv) < nb) {
-                        float a1[1] = {cok ? rs[j] : 0.f};
-                        c2_slot_sum<1>(a1, lp);
-                        const float gm1 = a1[0] * inv_gs, d = rs[j] - gm1;
-                        a1[0] = cok ? rm2[j] + flin * (d * d) : 0.f;
-                        c2_slot_sum<1>(a1, lp);
-                        gmr[j] = gm1; gscr[j] = ga * (1.f / sqrtf(a1[0] * inv_cnt + 1e-5f));
-                    }
-                }
-#pragma unroll
-                for (int lev = LOG2VEC - 1; lev >= 0; --lev)
-                    if (lev < lv) {
-#pragma unroll
-                        for (int j = 0; j < VEC; j += 2 << lev) { gmr[j + (1 << lev)] = gmr[j]; gscr[j + (1 << lev)] = gscr[j]; }
-                    }
-#else
                 if (lv == 0) group_stats(std::integral_constant<int, 1>());
                 else if (lv == 1) group_stats(std::integral_constant<int, 2>());
                 else if (lv == 2) group_stats(std::integral_constant<int, 4>());
                 else if (lv == 3 || VEC == 8) group_stats(std::integral_constant<int, 8>());
                 else group_stats(std::integral_constant<int, VEC>());
-#endif
                 C2_STAMP_FIRST(2);
                 C2_STAMP_FIRST(3);
 #else
@@ -1230,9 +1139,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (prev == A.KS - 1) ? 1 : 0;
             if (last) {
-#if !SURFD_C2_SC1_REDUCE
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
                 __hip_atomic_store(A.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             *flag = last;
@@ -1825,13 +1732,8 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
 #else
 #define C2_CFG_STAMPS 0
 #endif
-#if defined(SURFD_C2_PFN_NOLOAD) || defined(SURFD_C2_PFN_EARLYUSE) || defined(SURFD_C2_DBG_CLEARLDS) || defined(SURFD_C2_DBG_WAITALL) || defined(SURFD_C2_GNW_NOPK) || defined(SURFD_C2_GNW_ROWWISE) || defined(SURFD_C2_GNW_LIVEONLY)
-#define C2_CFG_DEVAIDS 1
-#else
-#define C2_CFG_DEVAIDS 0
-#endif
-#define C2_UNSAFE_COUNT ((SURFD_C2_GNW != 1) + (SURFD_C2_GNPAD < 1) + (SURFD_C2_SC1_REDUCE != 0) + (SURFD_C2_LAT_D != 2) + (SURFD_C2_PFN_DMA != 0) + \
-                         (SURFD_C2_BPIPE == 2) + (C2_CFG_ABLATE != 0) + (C2_CFG_POISON != 0) + (C2_CFG_PROBE != 0) + (C2_CFG_DEVAIDS != 0))
+#define C2_UNSAFE_COUNT ((SURFD_C2_GNW != 1) + (SURFD_C2_GNPAD < 1) + (SURFD_C2_LAT_D != 2) + \
+                         (SURFD_C2_BPIPE == 2) + (C2_CFG_ABLATE != 0) + (C2_CFG_POISON != 0) + (C2_CFG_PROBE != 0))
 #if !defined(SURFD_ALLOW_UNSAFE_VARIANTS)
 #if SURFD_C2_GNW != 1
 #error "SURFD_C2_GNW=0 (GroupNorm statistics through the LDS exchange) gives timing-dependent wrong 1/sigma values when workgroups share a CU (profiles/r06_conv2_instability.md); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
@@ -1839,29 +1741,22 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
 #if SURFD_C2_GNPAD < 1
 #error "SURFD_C2_GNPAD=0: the in-wave GroupNorm reductions without wait states are NOT bit-stable run to run (profiles/r05_loop_experiments.md section 3, profiles/r06_conv2_instability.md); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
 #endif
-#if SURFD_C2_SC1_REDUCE != 0
-#error "SURFD_C2_SC1_REDUCE=1 reads split-K partials without the acquire: stale L2 copies (profiles/r05_loop_experiments.md section 3); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
-#endif
 #if SURFD_C2_LAT_D != 2
 #error "SURFD_C2_LAT_D != 2 is not a validated configuration of the latency form (profiles/r05_loop_experiments.md section 1); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
-#endif
-#if SURFD_C2_PFN_DMA != 0
-#error "SURFD_C2_PFN_DMA=1: M0's 16-bit LDS base wraps in the two-per-CU forms (the word lands in the slab); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
 #endif
 #if SURFD_C2_BPIPE == 2
 #error "SURFD_C2_BPIPE=2 is the control of an experiment (not bit-stable with SURFD_C2_GNW, profiles/r06_conv2_instability.md); -DSURFD_ALLOW_UNSAFE_VARIANTS builds it anyway"
 #endif
-#if C2_CFG_ABLATE != 0 || C2_CFG_POISON != 0 || C2_CFG_PROBE != 0 || C2_CFG_DEVAIDS != 0
-#error "developer aids of conv_f16x2.hip (SURFD_C2_ABLATE / _DBG_* / _PROBE / _PFN_NOLOAD ...) change results or timing; -DSURFD_ALLOW_UNSAFE_VARIANTS builds them anyway"
+#if C2_CFG_ABLATE != 0 || C2_CFG_POISON != 0 || C2_CFG_PROBE != 0
+#error "developer aids of conv_f16x2.hip (SURFD_C2_ABLATE / _DBG_POISON / _PROBE) change results or timing; -DSURFD_ALLOW_UNSAFE_VARIANTS builds them anyway"
 #endif
 #endif
 const char *conv2_build_config() {
     return "C2_GNW=" C2_STR(SURFD_C2_GNW) " C2_BPIPE=" C2_STR(SURFD_C2_BPIPE) " C2_GNPAD=" C2_STR(SURFD_C2_GNPAD) " C2_PFN=" C2_STR(SURFD_C2_PFN) " C2_PFN_FORMS=" C2_STR(SURFD_C2_PFN_FORMS)
-           " C2_PFN_N=" C2_STR(SURFD_C2_PFN_N) " C2_PFN_DMA=" C2_STR(SURFD_C2_PFN_DMA) " C2_SC1_REDUCE=" C2_STR(SURFD_C2_SC1_REDUCE) " C2_KAPF=" C2_STR(SURFD_C2_KAPF)
+           " C2_PFN_N=" C2_STR(SURFD_C2_PFN_N) " C2_KAPF=" C2_STR(SURFD_C2_KAPF)
            " C2_FAST_RCP=" C2_STR(SURFD_C2_FAST_RCP) " C2_EPI_LATE=" C2_STR(SURFD_C2_EPI_LATE) " C2_LAT_D=" C2_STR(SURFD_C2_LAT_D) " C2_DEEP_D=" C2_STR(SURFD_C2_DEEP_D)
            " C2_LEAN_WAVES=" C2_STR(SURFD_C2_LEAN_WAVES) " C2_LEAN_U=" C2_STR(SURFD_C2_LEAN_U) " C2_PLANE_LEAN=" C2_STR(SURFD_C2_PLANE_LEAN)
-           " C2_ABLATE=" C2_STR(C2_CFG_ABLATE) " C2_DBG_POISON=" C2_STR(C2_CFG_POISON) " C2_PROBE=" C2_STR(C2_CFG_PROBE) " C2_STAMPS=" C2_STR(C2_CFG_STAMPS)
-           " C2_DEVAIDS=" C2_STR(C2_CFG_DEVAIDS);
+           " C2_ABLATE=" C2_STR(C2_CFG_ABLATE) " C2_DBG_POISON=" C2_STR(C2_CFG_POISON) " C2_PROBE=" C2_STR(C2_CFG_PROBE) " C2_STAMPS=" C2_STR(C2_CFG_STAMPS);
 }
 int conv2_build_unsafe() { return C2_UNSAFE_COUNT; }
 

@@ -53,9 +53,9 @@ def test_version_and_no_device(lib):
 
 # the experiment macros of the kernel sources and the values the PRODUCT build carries: a library built with
 # anything else — SURFD_EXTRA_HIPCC_FLAGS, a variant copied over the product path — fails here, not in a 1e-3 error weeks later
-SHIPPED_BUILD = {"C2_GNW": "1", "C2_GNPAD": "4", "C2_PFN": "1", "C2_PFN_FORMS": "1", "C2_PFN_N": "1", "C2_PFN_DMA": "0", "C2_SC1_REDUCE": "0", "C2_KAPF": "1",
+SHIPPED_BUILD = {"C2_GNW": "1", "C2_GNPAD": "4", "C2_PFN": "1", "C2_PFN_FORMS": "1", "C2_PFN_N": "1", "C2_KAPF": "1",
                  "C2_FAST_RCP": "1", "C2_EPI_LATE": "1", "C2_LAT_D": "2", "C2_DEEP_D": "3", "C2_LEAN_WAVES": "3", "C2_LEAN_U": "2",
-                 "C2_PLANE_LEAN": "11264", "C2_ABLATE": "0", "C2_DBG_POISON": "0", "C2_PROBE": "0", "C2_STAMPS": "0", "C2_DEVAIDS": "0",
+                 "C2_PLANE_LEAN": "11264", "C2_ABLATE": "0", "C2_DBG_POISON": "0", "C2_PROBE": "0", "C2_STAMPS": "0",
                  "DEC_OVL": "0", "DEC_MIX": "1", "DEC_GRAD_W": "2", "DEC_GRAD_MIX": "0", "DEC_WS_AHEAD": "0", "DEC_REQ_EARLY": "2",
                  "DEC_FWD_STAGED": "0", "DEC_XCD_STAGGER": "0", "DEC_CLOCK": "1", "DEC_W_NT": "0", "DEC_STAMPS": "0"}
 
@@ -69,7 +69,7 @@ def test_shipped_library_is_built_with_the_default_configuration(lib):
     assert cfg == SHIPPED_BUILD, {k: (cfg.get(k), SHIPPED_BUILD.get(k)) for k in set(cfg) | set(SHIPPED_BUILD) if cfg.get(k) != SHIPPED_BUILD.get(k)}
 
 
-@pytest.mark.parametrize("flag", ["-DSURFD_C2_GNW=0", "-DSURFD_C2_GNPAD=0", "-DSURFD_C2_SC1_REDUCE=1", "-DSURFD_C2_LAT_D=3", "-DSURFD_C2_ABLATE=1", "-DSURFD_C2_BPIPE=2"])
+@pytest.mark.parametrize("flag", ["-DSURFD_C2_GNW=0", "-DSURFD_C2_GNPAD=0", "-DSURFD_C2_LAT_D=3", "-DSURFD_C2_ABLATE=1", "-DSURFD_C2_BPIPE=2", "-DSURFD_C2_PROBE"])
 def test_unsafe_variants_do_not_compile_without_the_override(flag):
     """The fence itself: the preprocessor stops a build that selects a variant recorded as wrong / not bit-stable (checked with
     the preprocessor alone, -E: seconds, no code generation), and -DSURFD_ALLOW_UNSAFE_VARIANTS lifts it."""

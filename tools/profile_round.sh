@@ -4,7 +4,7 @@
 # MI355X_MICROARCH.md prescribes) on a shortened run of the same kernels.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05prof; mkdir -p $O
+O=${PROF_DIR:-gpurun_out/r06prof}; mkdir -p $O
 # PMC_ONLY=1: only the counter passes (after a kernel-source change that leaves the timings of the committed runs valid)
 if [ -z "${PMC_ONLY:-}" ]; then
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_A
 # keep only the summaries (the raw traces are large)
 python - <<'PY'
 import csv, collections, glob, json, os
-O = "gpurun_out/r05prof"
+O = os.environ.get("PROF_DIR", "gpurun_out/r06prof")
 def agg(path, col):
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
