@@ -109,6 +109,9 @@ struct Conv2Args {
 #ifndef SURFD_C2_LEAN_U
 #define SURFD_C2_LEAN_U 2
 #endif
+#ifndef SURFD_C2_ZB
+#define SURFD_C2_ZB 4                  // split-K partial tiles in flight together in the last arriver's reduction
+#endif
 #ifndef SURFD_C2_LAT_D
 #define SURFD_C2_LAT_D 2
 #endif
@@ -1151,15 +1154,39 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             for (int t = 0; t < NCT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            for (int z = 0; z < A.KS; ++z) {
-                const float *src = A.part + (((size_t)z * A.nby + by) * A.ntiles + tile) * A.part_stride;
+            // the partial tiles of C2_ZB slices are requested together and summed in slice order (round 6).  One slice at a
+            // time — what the rolled loop of rounds 3-5 compiled to: four loads, a wait, the adds, the branch — is KS
+            // consecutive round trips to another XCD's write-through data (~1 us each: the split-K phase of the stamps, 3-7 us
+            // of a 20-30 us workgroup life at KS = 4 ... 9).  Loads past the last slice re-read it (unconditional, as everywhere
+            // in this kernel); the order of the additions, hence every bit of the result, is unchanged.
+#ifndef SURFD_C2_ZB
+#define SURFD_C2_ZB 4
+#endif
+            // Measured (one box, profiles/r06_loop_ab_split_k_batch.json; bits identical in every row): latency form 1.364 -> 1.338 ms
+            // per evaluation at 8 latents with four slices in flight (8: 1.346, 2: 1.375); the lean form gains nothing (three
+            // workgroups per CU already cover each other's round trips: 18.9 us either way) and at four slices spills its 168th
+            // register again, so it keeps one slice at a time — as does the two-column-tile form, which has no register to spare.
+            constexpr int C2_ZB = (LEAN || NT2) ? 1 : SURFD_C2_ZB;
+            for (int z0 = 0; z0 < A.KS; z0 += C2_ZB) {
+                f32x4 pv[C2_ZB][NCT][4];
 #pragma unroll
-                for (int t = 0; t < NCT; ++t)
+                for (int zz = 0; zz < C2_ZB; ++zz) {
+                    const int z = min(z0 + zz, A.KS - 1);
+                    const float *src = A.part + (((size_t)z * A.nby + by) * A.ntiles + tile) * A.part_stride;
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 pv = c2_load_partial(src + ((size_t)((NT2 ? t : ct) * 4 + r4) * 64 + lane) * 4);
+                    for (int t = 0; t < NCT; ++t)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[t][4 * r4 + q] += pv[q];
+                        for (int r4 = 0; r4 < 4; ++r4) pv[zz][t][r4] = c2_load_partial(src + ((size_t)((NT2 ? t : ct) * 4 + r4) * 64 + lane) * 4);
+                }
+#pragma unroll
+                for (int zz = 0; zz < C2_ZB; ++zz)
+                    if (z0 + zz < A.KS) {          // wave-uniform
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t)
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[t][4 * r4 + q] += pv[zz][t][r4][q];
                     }
             }
         }
@@ -1755,7 +1782,7 @@ const char *conv2_build_config() {
     return "C2_GNW=" C2_STR(SURFD_C2_GNW) " C2_BPIPE=" C2_STR(SURFD_C2_BPIPE) " C2_GNPAD=" C2_STR(SURFD_C2_GNPAD) " C2_PFN=" C2_STR(SURFD_C2_PFN) " C2_PFN_FORMS=" C2_STR(SURFD_C2_PFN_FORMS)
            " C2_PFN_N=" C2_STR(SURFD_C2_PFN_N) " C2_KAPF=" C2_STR(SURFD_C2_KAPF)
            " C2_FAST_RCP=" C2_STR(SURFD_C2_FAST_RCP) " C2_EPI_LATE=" C2_STR(SURFD_C2_EPI_LATE) " C2_LAT_D=" C2_STR(SURFD_C2_LAT_D) " C2_DEEP_D=" C2_STR(SURFD_C2_DEEP_D)
-           " C2_LEAN_WAVES=" C2_STR(SURFD_C2_LEAN_WAVES) " C2_LEAN_U=" C2_STR(SURFD_C2_LEAN_U) " C2_PLANE_LEAN=" C2_STR(SURFD_C2_PLANE_LEAN)
+           " C2_ZB=" C2_STR(SURFD_C2_ZB) " C2_LEAN_WAVES=" C2_STR(SURFD_C2_LEAN_WAVES) " C2_LEAN_U=" C2_STR(SURFD_C2_LEAN_U) " C2_PLANE_LEAN=" C2_STR(SURFD_C2_PLANE_LEAN)
            " C2_ABLATE=" C2_STR(C2_CFG_ABLATE) " C2_DBG_POISON=" C2_STR(C2_CFG_POISON) " C2_PROBE=" C2_STR(C2_CFG_PROBE) " C2_STAMPS=" C2_STR(C2_CFG_STAMPS);
 }
 int conv2_build_unsafe() { return C2_UNSAFE_COUNT; }
