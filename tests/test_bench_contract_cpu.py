@@ -143,3 +143,10 @@ def test_committed_driver_line_carries_the_round_6_fields():
     d = json.load(open(newest))
     assert 0 < d["strict_c3"]["roofline"]["frac"] < 1 and d["strict_c3"]["roofline"]["bound"] == "hbm"
     assert "traffic_over_algorithmic" in d["roofline_loop"] and "unsafe_variants=0" in d["config"]["build_flags"]
+    # round 6, second half: the strict pass runs the headline's own steps (same shapes) and says where a request's time goes
+    s = d["strict_c3"]
+    assert s["steps_sampled"] == list(range(d["steps"])) and s["requests"] == d["steps"]
+    assert abs(s["decoder_fwd_queries_per_shape"] / s["headline_decoder_fwd_queries_per_shape"] - 1.0) < 0.02
+    parts = s["reverse_loop_s_per_request"] + s["decoder_fwd_s_per_request"] + s["decoder_fwd_bwd_s_per_request"] + s["other_s_per_request"]
+    assert parts == pytest.approx(s["latency_s_per_request"], rel=1e-6) and 0 <= s["other_s_per_request"] < 0.1 * s["latency_s_per_request"]
+    assert d["roofline"]["traffic"] is not None          # the committed PMC profile names the kernel sources this line was measured on
