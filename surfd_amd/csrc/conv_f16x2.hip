@@ -150,6 +150,25 @@ __device__ __forceinline__ float silu2(float v) {
 #endif
 }
 
+// four values at once: the multiplications and the addition two per instruction, the four transcendental pairs independent of
+// each other (the scalar form compiled to one dependent chain per value on one pair of registers: 11 instructions, two of them
+// quarter-rate, nothing to overlap them with on a SIMD that holds one wave).  Same operations per element as silu2: same bits.
+__device__ __forceinline__ void silu2_x4(f32x4 &v) {
+#if SURFD_C2_FAST_RCP
+    const f32x2 c = {-0x1.715476p+0f, -0x1.715476p+0f}, one = {1.f, 1.f};
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f32x2 ta = a * c, tb = b * c;
+    f32x2 ea = {__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1])}, eb = {__builtin_amdgcn_exp2f(tb[0]), __builtin_amdgcn_exp2f(tb[1])};
+    ea = one + ea; eb = one + eb;
+    const f32x2 ra = {__builtin_amdgcn_rcpf(ea[0]), __builtin_amdgcn_rcpf(ea[1])}, rb = {__builtin_amdgcn_rcpf(eb[0]), __builtin_amdgcn_rcpf(eb[1])};
+    const f32x2 ya = a * ra, yb = b * rb;
+    v[0] = ya[0]; v[1] = ya[1]; v[2] = yb[0]; v[3] = yb[1];
+#else
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = silu2(v[k]);
+#endif
+}
+
 // Kernel-argument prefetch.  Conv2Args is 6-7 cache lines of kernarg segment; with 106 SGPRs the compiler fetches it in
 // seven batches, each behind an s_waitcnt lgkmcnt(0) and each touching lines the scalar cache has not seen in this launch
 // (the segment was last read one graph replay = 553 MB of weight stream ago): seven dependent misses before the first
@@ -868,14 +887,35 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #if !SURFD_C2_GNW
                 if constexpr (ALIAS) lds_bar();
 #endif
-                if (cok) {
+                if (cok && !SLIM) {
+                    // two values per instruction (v_pk_add / v_pk_mul: the same IEEE operations per element, same bits) and the
+                    // wave-uniform `act` decided once, not per value.  Not in the register-lean forms (the lean kernel's 168 and the
+                    // 64-position wide kernel's 256 registers have no room for the independent temporaries: 11 / 55 spills)
+                    const f32x2 be2 = {be, be};
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const f32x2 gm2 = {gmr[j], gmr[j]}, gs2 = {gscr[j], gscr[j]};
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            const f32x2 x = {v[j][k], v[j][k + 1]};
+                            const f32x2 w = (x - gm2) * gs2 + be2;
+                            v[j][k] = w[0]; v[j][k + 1] = w[1];
+                        }
+                    }
+#if !(defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 3)  // developer aid 3: no SiLU
+                    if (act) {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) silu2_x4(v[j]);
+                    }
+#endif
+                } else if (cok) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
                         const float gm = gmr[j], gsc = gscr[j];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float w = (v[j][k] - gm) * gsc + be;
-#if !(defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 3)  // developer aid 3: no SiLU
+#if !(defined(SURFD_C2_ABLATE) && SURFD_C2_ABLATE == 3)
                             if (act) w = silu2(w);
 #endif
                             v[j][k] = w;
@@ -883,10 +923,15 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                     }
                 }
             } else if (act) {
+                if constexpr (!SLIM) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j)
+                    for (int j = 0; j < VEC; ++j) silu2_x4(v[j]);
+                } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[j][k] = silu2(v[j][k]);
+                    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[j][k] = silu2(v[j][k]);
+                }
             }
             // ---- split and write the slab [batch row][position][channel]; zero halo positions and padded channels.
             //      Two positions at a time: one packed conversion per pair, the halves stored with ds_write_b16 /
