@@ -115,6 +115,9 @@ struct Conv2Args {
 #ifndef SURFD_C2_LAT_D
 #define SURFD_C2_LAT_D 2
 #endif
+#ifndef SURFD_C2_DIST
+#define SURFD_C2_DIST 1                // latency form: k-part reduction, split-K hand-off and epilogue distributed over the k-part waves (see the kernel)
+#endif
 #ifndef SURFD_C2_DEEP_D
 #define SURFD_C2_DEEP_D 3
 #endif
@@ -720,11 +723,42 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             }
         }
     };
+    // Latency form, distributed tail (SURFD_C2_DIST, round 6): the k-parts of a column tile leave their partial tiles in LDS and wave
+    // kpart then owns the accumulator registers [4 q, 4 q + 4) of the quarter-blocks q in [kpart * QN, (kpart + 1) * QN), QN = 4 / KP
+    // (rows 8 q + 4 (lane >> 5) + 0..3 of the tile): it sums them over the k-parts in k-part order (kp = 0 first: the same additions
+    // in the same order as the one-owner form, same bits), publishes / gathers exactly those rows in a split K, and finishes them —
+    // the reduction, the hand-off reads and the epilogue of a tile are four waves' work instead of one's, and a lane requests 6 or
+    // 12 epilogue operands instead of 24.
+#if defined(SURFD_C2_PROBE)
+    constexpr bool DIST = false;          // the probe build reads the one-owner form's registers
+#else
+    constexpr bool DIST = !WT && SURFD_C2_DIST;
+#endif
+    const int QN = 4 >> log2kp;           // quarter-blocks per wave in the distributed tail (1 or 2)
+    f32x4 dpre_b[2], dpre_e[2];
+    float dpre_r[2][4];
+    auto request_epilogue_dist = [&]() {
+        const int cmax4 = ((A.Cout + 3) & ~3) - 4;
+        const int m = min(ct * 32 + (lane & 31), M - 1) + m_off;
+        const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int q = kpart * QN + min(qq, QN - 1);
+            const int cob = min(tile * 32 + 8 * q + 4 * (lane >> 5), cmax4);
+            dpre_b[qq] = *reinterpret_cast<const f32x4 *>(A.bias + cob);
+            dpre_e[qq] = *reinterpret_cast<const f32x4 *>(embp + b * A.emb_bstride + cob);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = min(cob + k, A.Cout - 1);
+                dpre_r[qq][k] = A.res[b * A.res_bstride + (long)co * A.res_cstride + l * A.res_lstride];
+            }
+        }
+    };
     // SURFD_C2_EPI_LATE (default): every form requests the epilogue operands after the K loop.  Requested here they put 24 more
     // vector-memory instructions per lane in front of the wait for the operand (the wave is busy issuing for ~2.6 us while the
     // operand is back after ~1.3); after the K loop their round trip hides behind the k-part reduction and the split-K hand-off
     constexpr bool EPI_LATE = SLIM || SURFD_C2_EPI_LATE;
-    if constexpr (!EPI_LATE) request_epilogue();
+    if constexpr (!EPI_LATE && !DIST) request_epilogue();
     bool saturated = false;
     C2_STAMP(1);
 #ifdef SURFD_C2_PROBE
@@ -952,6 +986,32 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
 #endif
             if (cok) {
                 float amax = 0.f;
+                // the (wave-uniform) upsampling decided once, not per pair of positions: a branch per pair is sixteen basic blocks the
+                // scheduler cannot interleave across (SURFD_C2_UPS_HOIST; not in the register-lean forms)
+                auto split_rows = [&](auto upsc) {
+                    constexpr bool UPS = decltype(upsc)::value;
+                    constexpr int RS = UPS ? 2 : 1;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const int i = rowbase + (j >> lv), jj = j & (vpr - 1);
+                        if (i < nb) {
+                            _Float16 *row = slab + (i * A.Lsl + pad + RS * 4 * jj) * cs + c;
+#pragma unroll
+                            for (int k = 0; k < 4; k += 2) {
+                                amax = fmaxf(amax, fmaxf(fabsf(v[j][k]), fabsf(v[j][k + 1])));
+                                const f32x2 w = {__builtin_amdgcn_fmed3f(v[j][k], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[j][k + 1], -65504.f, 65504.f)};
+                                const f16x2 h = __builtin_convertvector(w, f16x2);
+                                const f32x2 hf = __builtin_convertvector(h, f32x2);
+                                const f16x2 lo = __builtin_convertvector(w - hf, f16x2);
+                                _Float16 *d0 = row + (k * RS) * cs, *d1 = d0 + RS * cs;
+                                d0[0] = h[0]; d0[PLANE] = lo[0];
+                                d1[0] = h[1]; d1[PLANE] = lo[1];
+                                if constexpr (UPS) { d0[cs] = h[0]; d0[cs + PLANE] = lo[0]; d1[cs] = h[1]; d1[cs + PLANE] = lo[1]; }
+                            }
+                        }
+                    }
+                };
+                if constexpr (SLIM) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int i = rowbase + (j >> lv), jj = j & (vpr - 1);
@@ -970,6 +1030,9 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                             if (ups) { d0[cs] = h[0]; d0[cs + PLANE] = lo[0]; d1[cs] = h[1]; d1[cs + PLANE] = lo[1]; }
                         }
                     }
+                }
+                } else {
+                    if (ups) split_rows(std::true_type{}); else split_rows(std::false_type{});
                 }
                 saturated |= amax > 65504.f;
             }
@@ -1126,10 +1189,102 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
             issue_operand(ch, v, ga, be);
         }
     }
-    if constexpr (EPI_LATE) request_epilogue();      // round trip hidden behind the split-K hand-off (or the other workgroups of the CU)
+    if constexpr (DIST) request_epilogue_dist();
+    else if constexpr (EPI_LATE) request_epilogue();      // round trip hidden behind the split-K hand-off (or the other workgroups of the CU)
     if (saturated) atomicAdd(A.sat, 1u);
     C2_STAMP(6);
 
+    if constexpr (DIST) {
+        // ---- distributed tail of the latency form (see SURFD_C2_DIST above) ----
+        lds_bar();
+        {
+            float *dst = red + (kpart * nct + ct) * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = ONE_ACC ? acc_hh[0][r] : acc_sm[0][r] + acc_hh[0][r];
+        }
+        lds_bar();
+        f32x4 val[2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int q = kpart * QN + min(qq, QN - 1);
+            const float *srcp = red + ct * 1024 + (4 * q) * 64 + lane;
+            f32x4 t = {srcp[0], srcp[64], srcp[128], srcp[192]};
+            for (int kp = 1; kp < KP; ++kp) {
+                const float *sp = srcp + kp * nct * 1024;
+                t[0] += sp[0]; t[1] += sp[64]; t[2] += sp[128]; t[3] += sp[192];
+            }
+            val[qq] = t;
+        }
+        C2_STAMP(7);
+        if (A.KS > 1) {
+            const size_t slot = (size_t)by * A.nrt + rg;
+            float *mine = A.part + (((size_t)kz * A.nby + by) * A.ntiles + tile) * A.part_stride;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+                if (qq < QN) {
+                    float *dst = mine + ((size_t)(ct * 4 + kpart * QN + qq) * 64 + lane) * 4;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(val[qq]) : "memory");
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int *flag = reinterpret_cast<int *>(red + 4 * 1024);
+            if (tid == 0) {
+                const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = (prev == A.KS - 1) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __hip_atomic_store(A.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            // the partial tiles of DZB slices in flight together, summed in slice order (as SURFD_C2_ZB in the one-owner form)
+            constexpr int DZB = 8;
+            val[0] = f32x4{0.f, 0.f, 0.f, 0.f}; val[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const size_t zstride = (size_t)A.nby * A.ntiles * A.part_stride;
+            const float *src0 = A.part + ((size_t)by * A.ntiles + tile) * A.part_stride + ((size_t)(ct * 4 + kpart * QN) * 64 + lane) * 4;
+            for (int z0 = 0; z0 < A.KS; z0 += DZB) {
+                f32x4 pv[DZB][2];
+#pragma unroll
+                for (int zz = 0; zz < DZB; ++zz) {
+                    const int z = min(z0 + zz, A.KS - 1);
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) pv[zz][qq] = c2_load_partial(src0 + (size_t)z * zstride + (size_t)min(qq, QN - 1) * 256);
+                }
+#pragma unroll
+                for (int zz = 0; zz < DZB; ++zz)
+                    if (z0 + zz < A.KS) {
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[qq][e] += pv[zz][qq][e];
+                    }
+            }
+        }
+        C2_STAMP(8);
+        {
+            const int ml = ct * 32 + (lane & 31), m = ml + m_off;
+            const bool mok = ml < M;
+            const int b = b0 + (m >> A.log2Lout), l = m & (A.Lout - 1);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = tile * 32 + e + 8 * (kpart * QN + qq) + 4 * (lane >> 5);
+                    if (qq < QN && mok && co < A.Cout) {
+                        const float o = val[qq][e] * inv_sc + ((dpre_b[qq][e] + (A.has_emb ? dpre_e[qq][e] : 0.f)) + (A.has_res ? dpre_r[qq][e] : 0.f));
+                        A.out[b * A.out_bstride + (long)co * A.Lout + l] = o;
+                        if constexpr (LF) {
+                            const long n = (long)A.B * A.Cout * A.Lout, ee = ((long)b * A.Cout + co) * A.Lout + l;
+                            const float xn = loop_update(lfv.sampler, lfv.clip, lfv.eta, lfrow, o, lfv.x[ee], lfv.lp->noise[(long)(1 + lfk) * n + ee]);
+                            lfv.x[ee] = xn;
+                            if (lfv.lp->traj) lfv.lp->traj[(long)lfk * n + ee] = xn;
+                        }
+                    }
+                }
+        }
+    } else {
     // ---- sum the two product streams, then the k-parts of the workgroup (LDS) ------------------------
     f32x16 acc[NCT];
 #pragma unroll
@@ -1182,7 +1337,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int *flag = reinterpret_cast<int *>(ALIAS ? red : red + 3 * 1024);
+        int *flag = reinterpret_cast<int *>(ALIAS ? red : red + 4 * 1024);
         if (tid == 0) {
             const int prev = __hip_atomic_fetch_add(A.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (prev == A.KS - 1) ? 1 : 0;
@@ -1264,6 +1419,7 @@ __global__ __launch_bounds__(256, LEAN ? SURFD_C2_LEAN_WAVES : (VEC == 16 ? (WT 
                 }
             }
         }
+    }
     }
     if constexpr (LF) {
         // the last workgroup to get here advances the loop counter: every workgroup of this launch that reads it (above) has
@@ -1597,7 +1753,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
     A.off_red = (int)lds;
     if (lean || (wt && VEC == 16)) lds += 16;      // the split-K flag; the GroupNorm exchange arrays alias the slab (2 x 8 (16) KB + 2 KB <= 2 planes)
 #if SURFD_C2_GNW
-    else lds += (size_t)(3 * 1024 + 4) * sizeof(float);       // k-part reduction scratch + flag (the GroupNorm statistics need no LDS)
+    else lds += (size_t)(4 * 1024 + 4) * sizeof(float);       // k-part reduction scratch (latency form, distributed tail: every k-part leaves its tile) + flag
 #else
     else lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
 #endif
@@ -1667,7 +1823,7 @@ int launch_conv2(surfd_unet *u, const ConvPlan &c, int B, int L, const ConvLaunc
         lds = (lds + 15) & ~(size_t)15;
         A.plane = 15360; A.off_ex = (int)lds; A.off_red = (int)lds;
 #if SURFD_C2_GNW
-        lds += (size_t)(3 * 1024 + 4) * sizeof(float);
+        lds += (size_t)(4 * 1024 + 4) * sizeof(float);
 #else
         lds += std::max(((size_t)2 * VEC * 256 + 2 * 8 * 32) * sizeof(float), (size_t)(3 * 1024 + 4) * sizeof(float));
 #endif
@@ -1827,7 +1983,7 @@ const char *conv2_build_config() {
     return "C2_GNW=" C2_STR(SURFD_C2_GNW) " C2_BPIPE=" C2_STR(SURFD_C2_BPIPE) " C2_GNPAD=" C2_STR(SURFD_C2_GNPAD) " C2_PFN=" C2_STR(SURFD_C2_PFN) " C2_PFN_FORMS=" C2_STR(SURFD_C2_PFN_FORMS)
            " C2_PFN_N=" C2_STR(SURFD_C2_PFN_N) " C2_KAPF=" C2_STR(SURFD_C2_KAPF)
            " C2_FAST_RCP=" C2_STR(SURFD_C2_FAST_RCP) " C2_EPI_LATE=" C2_STR(SURFD_C2_EPI_LATE) " C2_LAT_D=" C2_STR(SURFD_C2_LAT_D) " C2_DEEP_D=" C2_STR(SURFD_C2_DEEP_D)
-           " C2_ZB=" C2_STR(SURFD_C2_ZB) " C2_LEAN_WAVES=" C2_STR(SURFD_C2_LEAN_WAVES) " C2_LEAN_U=" C2_STR(SURFD_C2_LEAN_U) " C2_PLANE_LEAN=" C2_STR(SURFD_C2_PLANE_LEAN)
+           " C2_ZB=" C2_STR(SURFD_C2_ZB) " C2_DIST=" C2_STR(SURFD_C2_DIST) " C2_LEAN_WAVES=" C2_STR(SURFD_C2_LEAN_WAVES) " C2_LEAN_U=" C2_STR(SURFD_C2_LEAN_U) " C2_PLANE_LEAN=" C2_STR(SURFD_C2_PLANE_LEAN)
            " C2_ABLATE=" C2_STR(C2_CFG_ABLATE) " C2_DBG_POISON=" C2_STR(C2_CFG_POISON) " C2_PROBE=" C2_STR(C2_CFG_PROBE) " C2_STAMPS=" C2_STR(C2_CFG_STAMPS);
 }
 int conv2_build_unsafe() { return C2_UNSAFE_COUNT; }

@@ -54,7 +54,7 @@ def test_version_and_no_device(lib):
 # the experiment macros of the kernel sources and the values the PRODUCT build carries: a library built with
 # anything else — SURFD_EXTRA_HIPCC_FLAGS, a variant copied over the product path — fails here, not in a 1e-3 error weeks later
 SHIPPED_BUILD = {"C2_GNW": "1", "C2_GNPAD": "4", "C2_PFN": "1", "C2_PFN_FORMS": "1", "C2_PFN_N": "1", "C2_KAPF": "1",
-                 "C2_FAST_RCP": "1", "C2_EPI_LATE": "1", "C2_LAT_D": "2", "C2_DEEP_D": "3", "C2_ZB": "4", "C2_LEAN_WAVES": "3", "C2_LEAN_U": "2",
+                 "C2_FAST_RCP": "1", "C2_EPI_LATE": "1", "C2_LAT_D": "2", "C2_DEEP_D": "3", "C2_ZB": "4", "C2_DIST": "1", "C2_LEAN_WAVES": "3", "C2_LEAN_U": "2",
                  "C2_PLANE_LEAN": "11264", "C2_ABLATE": "0", "C2_DBG_POISON": "0", "C2_PROBE": "0", "C2_STAMPS": "0",
                  "DEC_OVL": "0", "DEC_MIX": "1", "DEC_GRAD_W": "2", "DEC_GRAD_MIX": "0", "DEC_WS_AHEAD": "0", "DEC_REQ_EARLY": "2",
                  "DEC_FWD_STAGED": "0", "DEC_XCD_STAGGER": "0", "DEC_CLOCK": "1", "DEC_W_NT": "0", "DEC_STAMPS": "0"}
